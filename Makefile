@@ -1,0 +1,28 @@
+# Builds vq_amd/libvqhip.so (HIP, gfx950 only) and the CPU oracle.
+# hipcc cross-compiles without a GPU; the .so is git-ignored but travels with gpurun snapshots.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     := gfx950
+CSRC     := vq_amd/csrc
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unused-parameter -Iinclude
+OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_mfma.o $(CSRC)/synth.o
+LIB      := vq_amd/libvqhip.so
+
+all: $(LIB) oracle
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vq_common.h include/vqhip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/vq_common.h include/vqhip.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+oracle:
+	$(MAKE) -C oracle -s libvqoracle.so
+
+clean:
+	rm -f $(OBJS) $(LIB)
+	$(MAKE) -C oracle -s clean
+
+.PHONY: all oracle clean

@@ -1,0 +1,134 @@
+/*
+ * vqhip.h -- C ABI of the MI355X (gfx950) nearest-prototype library, libvqhip.
+ *
+ * This is the drop-in boundary for ONE path of GerritLuimstra/vq: batched distance
+ * computation + winner (argmin) assignment, i.e. the bodies of
+ *     find_closest_prototype              src/helpers.rs:55-77
+ *     find_closest_prototype_matched      src/helpers.rs:91-132
+ *     LGMLVQ::find_closest_local_prototype{,_matched}   src/lgmlvq/lgmlvq.rs:436-455, 468-506
+ * as they are driven by the six `predict` loops (src/vq/vq.rs:142-160, src/lvq/lvq.rs:193-211,
+ * src/glvq/glvq.rs:217-235, src/gmlvq/gmlvq.rs:270-290, src/lgmlvq/lgmlvq.rs:278-298,
+ * src/liramlvq/liramlvq.rs:287-307) and by the matched double call of the fit loops
+ * (src/glvq/glvq.rs:171-176, src/lgmlvq/lgmlvq.rs:194-199).
+ *
+ * The reference has no FFI of its own (pure Rust).  These are the entry points a Rust
+ * `extern "C"` block for this path would bind; INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all matrices row-major and contiguous
+ *   - every function returns VQHIP_OK (0) or a negative vqhip_status; nothing throws or
+ *     aborts across the boundary; vqhip_last_error() gives the text
+ *   - a context is bound to one GPU and serves one caller at a time (not re-entrant),
+ *     like `predict(&mut self)`.  One process per GPU; use one context per process/GPU.
+ *   - the context owns all device memory and pinned staging; the caller owns every pointer
+ *     it passes in; outputs are caller-allocated
+ *   - numbers: the reference is f64; the device computes in f32 (BASELINE.json north_star).
+ *     Euclidean results are ROOTED distances (src/helpers.rs:23), Omega results are the
+ *     SQUARED quadratic form (src/helpers.rs:44).
+ *   - winner semantics (src/helpers.rs:58-59,70): start at (index 0, +INF), replace on
+ *     strict '<' => lowest index wins ties, NaN/+INF never win, no eligible winner =>
+ *     index 0 with distance +INF.
+ */
+#ifndef VQHIP_H
+#define VQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vqhip_ctx vqhip_ctx; /* opaque */
+
+typedef enum {
+    VQHIP_OK = 0,
+    VQHIP_ERR_INVALID = -1,     /* bad argument (NULL, zero size, shape mismatch)             */
+    VQHIP_ERR_STATE = -2,       /* call order: prototypes / labels / omega not set            */
+    VQHIP_ERR_HIP = -3,         /* a HIP runtime call failed (text has hipGetErrorString)     */
+    VQHIP_ERR_NOMEM = -4,       /* host or device allocation failed                           */
+    VQHIP_ERR_UNSUPPORTED = -5  /* forced kernel policy cannot run this shape                 */
+} vqhip_status;
+
+/* Which kernel family serves assign calls.  AUTO picks the MFMA engine whenever the shape
+ * qualifies and the scalar kernels otherwise; the others are for tests and A/B timing. */
+typedef enum {
+    VQHIP_KERNEL_AUTO = 0,
+    VQHIP_KERNEL_SCALAR = 1,    /* one lane per sample, direct (x-w)^2 form, index-order sums  */
+    VQHIP_KERNEL_MFMA = 2       /* fp32 MFMA tile engine; VQHIP_ERR_UNSUPPORTED if not eligible */
+} vqhip_kernel_policy;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* Creates a context on HIP device `device`.  Replaces nothing in the reference (it has no
+ * device); it is what a Rust `Drop`-owning wrapper would hold inside the model struct. */
+int vqhip_create(int device, vqhip_ctx **out);
+int vqhip_destroy(vqhip_ctx *ctx);
+
+/* Text of the last failure on this context ("" if none).  ctx == NULL: last vqhip_create failure. */
+const char *vqhip_last_error(const vqhip_ctx *ctx);
+
+/* ---- model state (replaces the fields of src/lib.rs:30-34,186,226,270) ------------------ */
+
+/* Prototype vectors: `prototypes[j].vector` flattened, K x D (src/lib.rs:30-34).  Resets omega,
+ * local omegas and labels, which depend on K / D. */
+int vqhip_set_prototypes(vqhip_ctx *ctx, const float *W, uint32_t K, uint32_t D);
+
+/* Prototype class ids: `prototypes[j].name` interned to dense ids (src/helpers.rs:113 compares
+ * the strings by value; equal ids <=> equal names).  Needed only by the matched calls. */
+int vqhip_set_labels(vqhip_ctx *ctx, const uint32_t *cls, uint32_t K);
+
+/* Global Omega, M x D: GMLVQ `omega` (src/lib.rs:186, M == D) or LiRaMLVQ `omega`
+ * (src/lib.rs:270, M = max_rank).  Om == NULL clears it (back to Euclidean). */
+int vqhip_set_omega(vqhip_ctx *ctx, const float *Om, uint32_t M, uint32_t D);
+
+/* Local Omegas, K x M x D: LGMLVQ `omegas[j]` (src/lib.rs:226).  Oms == NULL clears. */
+int vqhip_set_local_omegas(vqhip_ctx *ctx, const float *Oms, uint32_t K, uint32_t M, uint32_t D);
+
+int vqhip_set_kernel_policy(vqhip_ctx *ctx, int policy /* vqhip_kernel_policy */);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+
+/* find_closest_prototype for N samples (src/helpers.rs:55-77; local Omegas:
+ * src/lgmlvq/lgmlvq.rs:436-455).  X is N x D.  idx_out[i] = winner index, dist_out[i] = its
+ * distance (rooted for Euclidean, squared for Omega models); dist_out may be NULL.
+ * Host-pointer form: samples go up in pinned, double-buffered chunks. */
+int vqhip_assign(vqhip_ctx *ctx, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out);
+
+/* Same with device-resident X / outputs, enqueued on `stream` (a hipStream_t; NULL = the
+ * default stream) without host synchronisation. */
+int vqhip_assign_device(vqhip_ctx *ctx, const float *dX, uint64_t N, uint32_t *didx_out,
+                        float *ddist_out, void *stream);
+
+/* find_closest_prototype_matched, both calls of the fit loop at once (src/helpers.rs:91-132 as
+ * called at src/glvq/glvq.rs:171-176; local: src/lgmlvq/lgmlvq.rs:468-506 as called at :194-199).
+ * y[i] = class id of sample i.  jpos/dpos: nearest prototype with cls == y[i];
+ * jneg/dneg: nearest with cls != y[i].  Any output pointer may be NULL. */
+int vqhip_assign_matched(vqhip_ctx *ctx, const float *X, const uint32_t *y, uint64_t N,
+                         uint32_t *jpos, float *dpos, uint32_t *jneg, float *dneg);
+int vqhip_assign_matched_device(vqhip_ctx *ctx, const float *dX, const uint32_t *dy, uint64_t N,
+                                uint32_t *djpos, float *ddpos, uint32_t *djneg, float *ddneg,
+                                void *stream);
+
+/* ---- introspection / measurement support ------------------------------------------------- */
+
+/* Name of the kernel family the last assign call on this context used ("scalar", "mfma_euclid",
+ * "mfma_omega", "mfma_local", ...).  For tests and bench reports. */
+const char *vqhip_last_kernel(const vqhip_ctx *ctx);
+
+/* Counter-based synthetic data: value(seed, stream, i) in [-1, 1) as f32.
+ * The host and device fills produce identical bits, so the CPU checker can regenerate any index
+ * range of a device-resident matrix.  out[i] = base_scale * (base ? base[(first+i) % base_len] : 0)
+ *                                            + scale * value(seed, stream, first + i)           */
+int vqhip_synth_fill_host(float *out, uint64_t count, uint64_t first, uint64_t seed, uint32_t stream_id,
+                          float scale, const float *base, uint64_t base_len);
+int vqhip_synth_fill_device(vqhip_ctx *ctx, float *dout, uint64_t count, uint64_t first, uint64_t seed,
+                            uint32_t stream_id, float scale, const float *dbase, uint64_t base_len,
+                            void *stream);
+
+const char *vqhip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQHIP_H */

@@ -1,0 +1,241 @@
+"""GPU: parity of the HIP path (through the C ABI) with the f64 oracle.
+
+Bar: winner indices identical to the oracle (near-ties, relative gap < 1e-5,
+flagged and counted), winner distances within 1e-5 relative.  Euclidean distances rooted, Omega
+distances squared (src/helpers.rs:23,44).  Tolerances are written out in tests/parity.py.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+import parity
+from conftest import assert_dist_close, intern_names, load_kat
+from vq_amd import KERNEL_AUTO, KERNEL_MFMA, KERNEL_SCALAR, Context, VqhipError, synth
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_kat()
+POLICIES = [KERNEL_SCALAR, KERNEL_AUTO]
+POLICY_IDS = ["scalar", "auto"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def _load_case(ctx, case, with_labels=False):
+    W = np.array(case["prototypes"], dtype=np.float32)
+    ctx.set_prototypes(W)
+    table = intern_names(case["proto_names"])
+    if with_labels:
+        ctx.set_labels(np.array([table[n] for n in case["proto_names"]], dtype=np.uint32))
+    if case["kind"] == "omega":
+        ctx.set_omega(np.array(case["omega"], dtype=np.float32))
+    elif case["kind"] == "local":
+        ctx.set_local_omegas(np.array(case["omega"], dtype=np.float32))
+    return table
+
+
+# ------------------------------------------------------------------ golden vectors via the C ABI
+
+@pytest.mark.parametrize("policy", POLICIES, ids=POLICY_IDS)
+@pytest.mark.parametrize("case", [c for c in CASES if "expect_idx" in c], ids=lambda c: c["name"])
+def test_kat_predict(ctx, case, policy):
+    ctx.set_kernel_policy(policy)
+    _load_case(ctx, case)
+    X = np.array(case["data"], dtype=np.float32)
+    idx, dist = ctx.assign(X)
+    assert idx.tolist() == case["expect_idx"]
+    assert [case["proto_names"][i] for i in idx] == case["expect_names"]       # src/vq/vq.rs:153-156
+    assert_dist_close(dist, case["expect_dist"], 1e-6, case["name"])           # f32 rounding of Omega = I/sqrt(2)
+
+
+def _matched(ctx, case, labels, exp, table):
+    X = np.array(case["data"], dtype=np.float32)
+    y = np.array([table.get(l, 0xFFFFFFFF) for l in labels], dtype=np.uint32)
+    jp, dp, jn, dn = ctx.assign_matched(X, y)
+    assert jp.tolist() == exp["expect_idx_matching"]
+    assert jn.tolist() == exp["expect_idx_non_matching"]
+    assert_dist_close(dp, exp["expect_dist_matching"], 1e-6)
+    assert_dist_close(dn, exp["expect_dist_non_matching"], 1e-6)
+
+
+@pytest.mark.parametrize("policy", POLICIES, ids=POLICY_IDS)
+@pytest.mark.parametrize("case", [c for c in CASES if "labels" in c], ids=lambda c: c["name"])
+def test_kat_matched(ctx, case, policy):
+    ctx.set_kernel_policy(policy)
+    table = _load_case(ctx, case, with_labels=True)
+    _matched(ctx, case, case["labels"], case, table)
+    if "also" in case:
+        _matched(ctx, case, case["also"]["labels"], case["also"], table)
+
+
+# ------------------------------------------------------------------ seeded models against the oracle
+
+SHAPES = [
+    # name, model, N, D, K, M, omega
+    ("c1_vq_iris_shape", "vq::VQ", 150, 4, 3, 0, "none"),
+    ("glvq_128x256", "GLVQ", 4099, 128, 256, 0, "none"),
+    ("glvq_ragged_d100_k37", "GLVQ", 777, 100, 37, 0, "none"),
+    ("glvq_d64_k70", "GLVQ", 1500, 64, 70, 0, "none"),
+    ("gmlvq_128x128", "GMLVQ", 2051, 128, 256, 128, "global"),
+    ("gmlvq_small_d12", "GMLVQ", 500, 12, 9, 12, "global"),
+    ("liramlvq_r16_d256", "LiRaMLVQ", 1111, 256, 128, 16, "global"),
+    ("liramlvq_r3_d20", "LiRaMLVQ", 300, 20, 6, 3, "global"),
+    ("lgmlvq_8x128", "LGMLVQ", 333, 128, 8, 128, "local"),
+    ("lgmlvq_small", "LGMLVQ", 257, 10, 5, 10, "local"),
+]
+
+
+def _model(shape):
+    name, model, N, D, K, M, om = shape
+    return synth.make_model(synth.Config(name, model, N, D, K, M=M, omega=om, classes=min(8, max(2, K // 2))))
+
+
+def _atol(m):
+    # Omega models subtract two f32 projections (Omega x - Omega w): absolute floor of a few ulps
+    # of the projected magnitude, squared distance scale.
+    return 0.0 if m.cfg.omega == "none" else 2e-6
+
+
+@pytest.mark.parametrize("policy", POLICIES, ids=POLICY_IDS)
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: s[0])
+def test_predict_parity(ctx, shape, policy):
+    m = _model(shape)
+    X = synth.samples_host(m, 0, m.cfg.N)
+    ctx.set_kernel_policy(policy)
+    synth.load_model(ctx, m, with_labels=False)
+    idx, dist = ctx.assign(X)
+    o_idx, o_best, o_second = oracle.assign(X, m.W, omega=m.omega, threads=8)
+    rep = parity.compare(idx, dist, o_idx, o_best, o_second, atol=_atol(m))
+    print(shape[0], ctx.last_kernel, rep)
+    assert rep.ok, str(rep)
+    # structured data: sample i was drawn around prototype i mod K (not guaranteed for Omega models)
+    if m.cfg.omega == "none" and m.cfg.D >= 32:
+        assert (idx == np.arange(m.cfg.N) % m.cfg.K).all()
+
+
+@pytest.mark.parametrize("policy", POLICIES, ids=POLICY_IDS)
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: s[0])
+def test_matched_parity(ctx, shape, policy):
+    m = _model(shape)
+    N = min(m.cfg.N, 1024)
+    X = synth.samples_host(m, 0, N)
+    y = synth.sample_labels(m, 0, N)
+    ctx.set_kernel_policy(policy)
+    synth.load_model(ctx, m, with_labels=True)
+    jp, dp, jn, dn = ctx.assign_matched(X, y)
+    for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+        o = oracle.assign(X, m.W, omega=m.omega, proto_cls=m.cls, labels=y, matching=matching, threads=8)
+        rep = parity.compare(j, d, *o, atol=_atol(m))
+        print(shape[0], "matching" if matching else "non-matching", ctx.last_kernel, rep)
+        assert rep.ok, str(rep)
+
+
+def test_unstructured_data_parity(ctx):
+    """Samples unrelated to the prototypes: small winner/runner-up gaps, the hard case for argmin."""
+    rng = np.random.default_rng(42)
+    D, K, N = 128, 256, 8192
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    o = oracle.assign(X, W, threads=8)
+    for policy in POLICIES:
+        ctx.set_kernel_policy(policy)
+        ctx.set_prototypes(W)
+        idx, dist = ctx.assign(X)
+        rep = parity.compare(idx, dist, *o)
+        print(ctx.last_kernel, rep)
+        assert rep.ok, str(rep)
+
+
+# ------------------------------------------------------------------ edge cases
+
+def test_empty_and_single(ctx):
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    W = np.array([[0.0, 0.0], [1.0, 1.0]], dtype=np.float32)
+    ctx.set_prototypes(W)
+    idx, dist = ctx.assign(np.zeros((0, 2), dtype=np.float32))
+    assert idx.shape == (0,) and dist.shape == (0,)
+    idx, dist = ctx.assign(np.array([[0.9, 0.9]], dtype=np.float32))
+    assert idx.tolist() == [1] and abs(dist[0] - math.sqrt(0.02)) < 1e-7
+
+
+def test_nan_and_inf_rows_inside_a_batch(ctx):
+    m = _model(("t", "GLVQ", 700, 128, 256, 0, "none"))
+    X = synth.samples_host(m, 0, 700).copy()
+    X[5, 17] = np.nan
+    X[300, 0] = np.inf
+    X[699, 127] = -np.inf
+    o = oracle.assign(X, m.W)
+    assert o[0][5] == 0 and o[0][300] == 0 and o[0][699] == 0       # helpers.rs:58-59,70
+    for policy in POLICIES:
+        ctx.set_kernel_policy(policy)
+        synth.load_model(ctx, m, with_labels=False)
+        idx, dist = ctx.assign(X)
+        rep = parity.compare(idx, dist, *o)
+        assert rep.ok, str(rep)
+        assert np.isinf(dist[[5, 300, 699]]).all()
+
+
+def test_call_order_errors(ctx):
+    c2 = Context(0)
+    try:
+        with pytest.raises(VqhipError) as e:
+            c2.D = 2
+            c2.assign(np.zeros((1, 2), dtype=np.float32))
+        assert e.value.code == -2 and "prototypes" in e.value.text
+        c2.set_prototypes(np.zeros((2, 2), dtype=np.float32))
+        with pytest.raises(VqhipError) as e:
+            c2.assign_matched(np.zeros((1, 2), dtype=np.float32), np.zeros(1, dtype=np.uint32))
+        assert e.value.code == -2 and "labels" in e.value.text
+        with pytest.raises(VqhipError):
+            c2.set_omega(np.zeros((2, 3), dtype=np.float32))        # D mismatch
+        with pytest.raises(ValueError):
+            c2.assign(np.zeros((1, 3), dtype=np.float32))           # "Data must have the same dimensions"
+    finally:
+        c2.close()
+
+
+# ------------------------------------------------------------------ device-resident path
+
+def test_device_path_equals_host_path_and_synth_matches(ctx):
+    import torch
+
+    m = _model(("t", "GLVQ", 5000, 128, 256, 0, "none"))
+    Xh = synth.samples_host(m, 1000, 5000)
+    Xd = synth.samples_device(ctx, m, 1000, 5000)
+    assert (Xd.cpu().numpy() == Xh).all()                           # generator: host bits == device bits
+    for policy in POLICIES:
+        ctx.set_kernel_policy(policy)
+        synth.load_model(ctx, m)
+        ih, dh = ctx.assign(Xh)
+        idd, ddd = ctx.assign(Xd)
+        torch.cuda.synchronize()
+        assert (idd.cpu().numpy().view(np.uint32) == ih).all()
+        assert (ddd.cpu().numpy() == dh).all()
+        y = torch.from_numpy(synth.sample_labels(m, 1000, 5000).view(np.int32)).cuda()
+        jp, dp, jn, dn = ctx.assign_matched(Xd, y)
+        hp = ctx.assign_matched(Xh, synth.sample_labels(m, 1000, 5000))
+        torch.cuda.synchronize()
+        for a, b in zip((jp, dp, jn, dn), hp):
+            assert (a.cpu().numpy().view(b.dtype) == b).all()
+
+
+def test_host_path_multi_chunk(ctx):
+    """More rows than one pinned staging buffer holds (D=4 -> 8M-row chunks): N spans 2+ chunks."""
+    m = _model(("t", "vq::VQ", 1, 4, 3, 0, "none"))
+    N = (128 << 20) // 16 * 2 + 12345
+    X = synth.samples_host(m, 0, N)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    synth.load_model(ctx, m, with_labels=False)
+    idx, dist = ctx.assign(X)
+    assert (idx == np.arange(N) % 3).all()
+    for lo in (0, N // 2 - 500, N - 1000):
+        o = oracle.assign(X[lo:lo + 1000], m.W)
+        rep = parity.compare(idx[lo:lo + 1000], dist[lo:lo + 1000], *o)
+        assert rep.ok, str(rep)

@@ -1,0 +1,176 @@
+"""Thin Python handle over the C ABI (include/vqhip.h).  PyTorch appears only as the owner of
+device memory and streams; numpy arrays take the pinned host path of the library."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VqhipError
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32)) if a is not None else None
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class Context:
+    """One GPU, one caller at a time (like `predict(&mut self)` in the reference)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.vqhip_create(int(device), C.byref(h))
+        if rc != 0:
+            raise VqhipError(rc, self._L.vqhip_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.K = self.D = self.M = 0
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vqhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise VqhipError(rc, self._L.vqhip_last_error(self._h).decode())
+
+    # -- model state
+    def set_prototypes(self, W):
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        if W.ndim != 2:
+            raise ValueError("prototypes must be K x D")
+        self._chk(self._L.vqhip_set_prototypes(self._h, _fp(W), W.shape[0], W.shape[1]))
+        self.K, self.D, self.M = W.shape[0], W.shape[1], 0
+
+    def set_labels(self, cls):
+        cls = np.ascontiguousarray(cls, dtype=np.uint32)
+        self._chk(self._L.vqhip_set_labels(self._h, _up(cls), cls.shape[0]))
+
+    def set_omega(self, omega):
+        if omega is None:
+            self._chk(self._L.vqhip_set_omega(self._h, None, 0, 0))
+            self.M = 0
+            return
+        om = np.ascontiguousarray(omega, dtype=np.float32)
+        if om.ndim != 2:
+            raise ValueError("omega must be M x D")
+        self._chk(self._L.vqhip_set_omega(self._h, _fp(om), om.shape[0], om.shape[1]))
+        self.M = om.shape[0]
+
+    def set_local_omegas(self, omegas):
+        if omegas is None:
+            self._chk(self._L.vqhip_set_local_omegas(self._h, None, 0, 0, 0))
+            self.M = 0
+            return
+        om = np.ascontiguousarray(omegas, dtype=np.float32)
+        if om.ndim != 3:
+            raise ValueError("local omegas must be K x M x D")
+        self._chk(self._L.vqhip_set_local_omegas(self._h, _fp(om), om.shape[0], om.shape[1], om.shape[2]))
+        self.M = om.shape[1]
+
+    def set_kernel_policy(self, policy: int):
+        self._chk(self._L.vqhip_set_kernel_policy(self._h, int(policy)))
+
+    @property
+    def last_kernel(self) -> str:
+        return self._L.vqhip_last_kernel(self._h).decode()
+
+    # -- hot path
+    def assign(self, X, want_dist: bool = True):
+        """find_closest_prototype for every row of X -> (idx, dist).
+        numpy in -> numpy out (pinned chunked uploads); CUDA torch tensor in -> torch tensors out,
+        enqueued on torch's current stream with no host synchronisation."""
+        if _is_torch(X):
+            return self._assign_torch(X, None, want_dist)
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        self._check_shape(X.shape)
+        N = X.shape[0]
+        idx = np.empty(N, dtype=np.uint32)
+        dist = np.empty(N, dtype=np.float32) if want_dist else None
+        self._chk(self._L.vqhip_assign(self._h, _fp(X), N, _up(idx), _fp(dist)))
+        return idx, dist
+
+    def assign_matched(self, X, y):
+        """Both fit-time searches -> (jpos, dpos, jneg, dneg)."""
+        if _is_torch(X):
+            return self._assign_torch(X, y, True)
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.uint32)
+        self._check_shape(X.shape)
+        N = X.shape[0]
+        if y.shape != (N,):
+            raise ValueError("y must have one class id per sample")
+        jp, jn = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.uint32)
+        dp, dn = np.empty(N, dtype=np.float32), np.empty(N, dtype=np.float32)
+        self._chk(self._L.vqhip_assign_matched(self._h, _fp(X), _up(y), N, _up(jp), _fp(dp), _up(jn), _fp(dn)))
+        return jp, dp, jn, dn
+
+    def assign_into(self, X, idx_out, dist_out=None, y=None, jneg_out=None, dneg_out=None):
+        """Device path with caller-provided torch output tensors (int32 storage for indices)."""
+        import torch
+
+        self._check_torch(X)
+        N = X.shape[0]
+        stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+
+        def p(t):
+            return C.c_void_p(t.data_ptr()) if t is not None else None
+
+        if y is None:
+            self._chk(self._L.vqhip_assign_device(self._h, p(X), N, p(idx_out), p(dist_out), stream))
+        else:
+            self._chk(self._L.vqhip_assign_matched_device(self._h, p(X), p(y), N, p(idx_out), p(dist_out),
+                                                          p(jneg_out), p(dneg_out), stream))
+
+    def _assign_torch(self, X, y, want_dist):
+        import torch
+
+        self._check_torch(X)
+        N = X.shape[0]
+        idx = torch.empty(N, dtype=torch.int32, device=X.device)
+        dist = torch.empty(N, dtype=torch.float32, device=X.device) if want_dist else None
+        if y is None:
+            self.assign_into(X, idx, dist)
+            return idx, dist
+        if not (y.is_cuda and y.dtype == torch.int32 and y.is_contiguous() and y.shape == (N,)):
+            raise ValueError("y must be a contiguous CUDA int32 tensor with one class id per sample")
+        jn = torch.empty(N, dtype=torch.int32, device=X.device)
+        dn = torch.empty(N, dtype=torch.float32, device=X.device)
+        self.assign_into(X, idx, dist, y, jn, dn)
+        return idx, dist, jn, dn
+
+    def _check_shape(self, shape):
+        if len(shape) != 2 or shape[1] != self.D:
+            raise ValueError(f"X must be N x {self.D}")
+
+    def _check_torch(self, X):
+        import torch
+
+        if not (X.is_cuda and X.dtype == torch.float32 and X.is_contiguous()):
+            raise ValueError("X must be a contiguous CUDA float32 tensor")
+        if X.device.index != self.device:
+            raise ValueError(f"X lives on cuda:{X.device.index}, the context on cuda:{self.device}")
+        self._check_shape(tuple(X.shape))

@@ -1,0 +1,438 @@
+// libvqhip: context, model upload, dispatch, pinned double-buffered host path.
+// The ABI is declared (with the reference citations) in include/vqhip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "vq_common.h"
+
+using namespace vq;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct Staging {                 // one of the two halves of the host-path pipeline
+    hipStream_t stream = nullptr;
+    float *hX = nullptr;     float *dX = nullptr;          // samples
+    uint32_t *hY = nullptr;  uint32_t *dY = nullptr;       // sample class ids (matched)
+    uint32_t *hI[2] = {nullptr, nullptr};  uint32_t *dI[2] = {nullptr, nullptr};
+    float *hD[2] = {nullptr, nullptr};     float *dD[2] = {nullptr, nullptr};
+};
+}  // namespace
+
+struct vqhip_ctx {
+    int device = 0;
+    std::string err;
+    const char *last_kernel = "none";
+    int policy = VQHIP_KERNEL_AUTO;
+
+    uint32_t K = 0, D = 0, M = 0;
+    int omega_kind = OMEGA_NONE;
+    std::vector<float> hW, hOm;
+    std::vector<uint32_t> hcls;
+
+    float *dW = nullptr;       // K x D
+    uint32_t *dcls = nullptr;  // K
+    float *dOm = nullptr;      // M x D  or  K x M x D
+    float *dP = nullptr;       // K x M: W . Omega^T (global Omega only)
+    float *dYproj = nullptr;   // scalar-path scratch: projected samples, chunk x M
+    size_t dYproj_cap = 0;
+
+    EngineModel *engine = nullptr;
+    bool engine_tried = false;
+    std::string engine_why;
+
+    Staging st[2];
+    size_t st_chunk = 0;       // samples per staging buffer
+    uint32_t st_D = 0;
+
+    int fail(int code, const std::string &msg)
+    {
+        err = msg;
+        return code;
+    }
+    int fail_hip(hipError_t e, const char *what)
+    {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? VQHIP_ERR_NOMEM : VQHIP_ERR_HIP;
+    }
+};
+
+#define HIPCHK(ctx, call)                                   \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return (ctx)->fail_hip(e_, #call); \
+    } while (0)
+
+namespace {
+
+void drop_engine(vqhip_ctx *c)
+{
+    engine_free(c->engine);
+    c->engine = nullptr;
+    c->engine_tried = false;
+    c->engine_why.clear();
+}
+
+void free_staging(vqhip_ctx *c)
+{
+    for (Staging &s : c->st) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        (void)hipHostFree(s.hX); (void)hipFree(s.dX);
+        (void)hipHostFree(s.hY); (void)hipFree(s.dY);
+        for (int j = 0; j < 2; ++j) {
+            (void)hipHostFree(s.hI[j]); (void)hipFree(s.dI[j]);
+            (void)hipHostFree(s.hD[j]); (void)hipFree(s.dD[j]);
+        }
+        hipStream_t keep = s.stream;
+        s = Staging();
+        s.stream = keep;
+    }
+    c->st_chunk = 0;
+    c->st_D = 0;
+}
+
+void free_omega(vqhip_ctx *c)
+{
+    (void)hipFree(c->dOm); c->dOm = nullptr;
+    (void)hipFree(c->dP);  c->dP = nullptr;
+    c->hOm.clear();
+    c->M = 0;
+    c->omega_kind = OMEGA_NONE;
+}
+
+template <class T>
+int upload(vqhip_ctx *c, T **dst, const T *src, size_t count)
+{
+    (void)hipFree(*dst);
+    *dst = nullptr;
+    HIPCHK(c, hipMalloc((void **)dst, count * sizeof(T)));
+    HIPCHK(c, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return VQHIP_OK;
+}
+
+// Makes sure the MFMA engine's tile images exist when the policy wants them.
+int prepare_engine(vqhip_ctx *c)
+{
+    if (c->policy == VQHIP_KERNEL_SCALAR) return VQHIP_OK;
+    if (!c->engine_tried) {
+        c->engine_tried = true;
+        hipError_t herr = hipSuccess;
+        c->engine = engine_build(c->hW, c->K, c->D, c->hOm, c->omega_kind, c->M, c->hcls, c->engine_why, herr);
+        if (herr != hipSuccess) return c->fail_hip(herr, "engine_build");
+    }
+    if (!c->engine && c->policy == VQHIP_KERNEL_MFMA)
+        return c->fail(VQHIP_ERR_UNSUPPORTED, "MFMA engine not eligible for this model: " + c->engine_why);
+    return VQHIP_OK;
+}
+
+// All kernels for one device-resident batch, enqueued on `s`.
+int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s)
+{
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
+    if (dy && c->hcls.empty()) return c->fail(VQHIP_ERR_STATE, "matched search needs vqhip_set_labels");
+    if (N == 0) return VQHIP_OK;
+    int rc = prepare_engine(c);
+    if (rc != VQHIP_OK) return rc;
+
+    if (c->engine) {
+        c->last_kernel = engine_name(c->engine);
+        HIPCHK(c, engine_assign(c->engine, dX, N, dy, out, s));
+        return VQHIP_OK;
+    }
+
+    c->last_kernel = "scalar";
+    if (c->omega_kind == OMEGA_NONE) {
+        HIPCHK(c, launch_assign_scalar(dX, N, c->D, c->dW, c->K, c->dcls, dy, /*rooted=*/true, out, s));
+    } else if (c->omega_kind == OMEGA_GLOBAL) {
+        // Project a chunk of samples into the M-dim space, then search there against W.Omega^T.
+        const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (64ull << 20) / (c->M * 4ull)));
+        if (c->dYproj_cap < chunk * c->M) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            (void)hipFree(c->dYproj);
+            c->dYproj = nullptr;
+            c->dYproj_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->dYproj, chunk * c->M * sizeof(float)));
+            c->dYproj_cap = chunk * c->M;
+        }
+        for (uint64_t off = 0; off < N; off += chunk) {
+            const uint64_t n = std::min(chunk, N - off);
+            Outputs o = out;
+            if (o.idx) o.idx += off;
+            if (o.dist) o.dist += off;
+            if (o.jneg) o.jneg += off;
+            if (o.dneg) o.dneg += off;
+            HIPCHK(c, launch_project_scalar(dX + off * c->D, n, c->D, c->dOm, c->M, c->dYproj, s));
+            HIPCHK(c, launch_assign_scalar(c->dYproj, n, c->M, c->dP, c->K, c->dcls, dy ? dy + off : nullptr,
+                                           /*rooted=*/false, o, s));
+        }
+    } else {
+        HIPCHK(c, launch_assign_local_scalar(dX, N, c->D, c->dW, c->K, c->dOm, c->M, c->dcls, dy, out, s));
+    }
+    return VQHIP_OK;
+}
+
+int ensure_staging(vqhip_ctx *c, size_t chunk, bool matched)
+{
+    if (c->st_chunk >= chunk && c->st_D == c->D && (!matched || c->st[0].hY)) return VQHIP_OK;
+    free_staging(c);
+    for (Staging &s : c->st) {
+        if (!s.stream) HIPCHK(c, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        HIPCHK(c, hipHostMalloc((void **)&s.hX, chunk * c->D * sizeof(float), hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void **)&s.dX, chunk * c->D * sizeof(float)));
+        HIPCHK(c, hipHostMalloc((void **)&s.hY, chunk * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(c, hipMalloc((void **)&s.dY, chunk * sizeof(uint32_t)));
+        for (int j = 0; j < 2; ++j) {
+            HIPCHK(c, hipHostMalloc((void **)&s.hI[j], chunk * sizeof(uint32_t), hipHostMallocDefault));
+            HIPCHK(c, hipMalloc((void **)&s.dI[j], chunk * sizeof(uint32_t)));
+            HIPCHK(c, hipHostMalloc((void **)&s.hD[j], chunk * sizeof(float), hipHostMallocDefault));
+            HIPCHK(c, hipMalloc((void **)&s.dD[j], chunk * sizeof(float)));
+        }
+    }
+    c->st_chunk = chunk;
+    c->st_D = c->D;
+    return VQHIP_OK;
+}
+
+// Host-pointer path: pinned, double-buffered chunks.  While the GPU works on chunk c (stream
+// c%2) the CPU packs chunk c+1 into the other pinned buffer and unpacks the results of c-1.
+int run_host(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, uint32_t *o0, float *d0, uint32_t *o1,
+             float *d1)
+{
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
+    if (y && c->hcls.empty()) return c->fail(VQHIP_ERR_STATE, "matched search needs vqhip_set_labels");
+    if (N == 0) return VQHIP_OK;
+    if (!X) return c->fail(VQHIP_ERR_INVALID, "X is NULL");
+    const size_t row = (size_t)c->D * sizeof(float);
+    size_t chunk = std::max<size_t>(1024, (128ull << 20) / row);     // <= 128 MiB of samples per buffer
+    chunk = (size_t)std::min<uint64_t>(chunk, N);
+    int rc = ensure_staging(c, chunk, y != nullptr);
+    if (rc != VQHIP_OK) return rc;
+    chunk = c->st_chunk;
+
+    const uint64_t nchunks = (N + chunk - 1) / chunk;
+    auto finish = [&](uint64_t ci) -> int {
+        Staging &s = c->st[ci & 1];
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+        const uint64_t off = ci * chunk, n = std::min<uint64_t>(chunk, N - off);
+        if (o0) std::memcpy(o0 + off, s.hI[0], n * sizeof(uint32_t));
+        if (d0) std::memcpy(d0 + off, s.hD[0], n * sizeof(float));
+        if (o1) std::memcpy(o1 + off, s.hI[1], n * sizeof(uint32_t));
+        if (d1) std::memcpy(d1 + off, s.hD[1], n * sizeof(float));
+        return VQHIP_OK;
+    };
+    for (uint64_t ci = 0; ci < nchunks; ++ci) {
+        Staging &s = c->st[ci & 1];
+        if (ci >= 2 && (rc = finish(ci - 2)) != VQHIP_OK) return rc;
+        const uint64_t off = ci * chunk, n = std::min<uint64_t>(chunk, N - off);
+        std::memcpy(s.hX, X + off * c->D, n * row);
+        HIPCHK(c, hipMemcpyAsync(s.dX, s.hX, n * row, hipMemcpyHostToDevice, s.stream));
+        if (y) {
+            std::memcpy(s.hY, y + off, n * sizeof(uint32_t));
+            HIPCHK(c, hipMemcpyAsync(s.dY, s.hY, n * sizeof(uint32_t), hipMemcpyHostToDevice, s.stream));
+        }
+        Outputs out{s.dI[0], s.dD[0], y ? s.dI[1] : nullptr, y ? s.dD[1] : nullptr};
+        rc = run_device(c, s.dX, n, y ? s.dY : nullptr, out, s.stream);
+        if (rc != VQHIP_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(s.hI[0], s.dI[0], n * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+        HIPCHK(c, hipMemcpyAsync(s.hD[0], s.dD[0], n * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        if (y) {
+            HIPCHK(c, hipMemcpyAsync(s.hI[1], s.dI[1], n * sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
+            HIPCHK(c, hipMemcpyAsync(s.hD[1], s.dD[1], n * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+        }
+    }
+    for (uint64_t ci = nchunks >= 2 ? nchunks - 2 : 0; ci < nchunks; ++ci)
+        if ((rc = finish(ci)) != VQHIP_OK) return rc;
+    return VQHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vqhip_create(int device, vqhip_ctx **out)
+{
+    if (!out) {
+        g_create_error = "out is NULL";
+        return VQHIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return VQHIP_ERR_HIP;
+    }
+    if (device < 0 || device >= count) {
+        g_create_error = "device index out of range";
+        return VQHIP_ERR_INVALID;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return VQHIP_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return VQHIP_ERR_HIP;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("libvqhip is built for gfx950 only; device is ") + prop.gcnArchName;
+        return VQHIP_ERR_UNSUPPORTED;
+    }
+    vqhip_ctx *c = new (std::nothrow) vqhip_ctx();
+    if (!c) {
+        g_create_error = "out of host memory";
+        return VQHIP_ERR_NOMEM;
+    }
+    c->device = device;
+    *out = c;
+    return VQHIP_OK;
+}
+
+int vqhip_destroy(vqhip_ctx *c)
+{
+    if (!c) return VQHIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_staging(c);
+    for (Staging &s : c->st)
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    drop_engine(c);
+    free_omega(c);
+    (void)hipFree(c->dW);
+    (void)hipFree(c->dcls);
+    (void)hipFree(c->dYproj);
+    delete c;
+    return VQHIP_OK;
+}
+
+const char *vqhip_last_error(const vqhip_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+const char *vqhip_last_kernel(const vqhip_ctx *c) { return c ? c->last_kernel : "none"; }
+
+const char *vqhip_version(void) { return "vqhip 0.1 (gfx950)"; }
+
+int vqhip_set_prototypes(vqhip_ctx *c, const float *W, uint32_t K, uint32_t D)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!W || K == 0 || D == 0) return c->fail(VQHIP_ERR_INVALID, "set_prototypes: W is NULL or K/D is 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    drop_engine(c);
+    free_omega(c);
+    (void)hipFree(c->dcls);
+    c->dcls = nullptr;
+    c->hcls.clear();
+    c->hW.assign(W, W + (size_t)K * D);
+    c->K = K;
+    c->D = D;
+    return upload(c, &c->dW, W, (size_t)K * D);
+}
+
+int vqhip_set_labels(vqhip_ctx *c, const uint32_t *cls, uint32_t K)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "set_labels before set_prototypes");
+    if (!cls || K != c->K) return c->fail(VQHIP_ERR_INVALID, "set_labels: cls is NULL or K differs from the prototypes");
+    HIPCHK(c, hipSetDevice(c->device));
+    drop_engine(c);
+    c->hcls.assign(cls, cls + K);
+    return upload(c, &c->dcls, cls, K);
+}
+
+int vqhip_set_omega(vqhip_ctx *c, const float *Om, uint32_t M, uint32_t D)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "set_omega before set_prototypes");
+    HIPCHK(c, hipSetDevice(c->device));
+    drop_engine(c);
+    free_omega(c);
+    if (!Om) return VQHIP_OK;
+    if (M == 0 || D != c->D) return c->fail(VQHIP_ERR_INVALID, "set_omega: M is 0 or D differs from the prototypes");
+    c->hOm.assign(Om, Om + (size_t)M * D);
+    c->M = M;
+    c->omega_kind = OMEGA_GLOBAL;
+    int rc = upload(c, &c->dOm, Om, (size_t)M * D);
+    if (rc != VQHIP_OK) return rc;
+    // P = W . Omega^T in f64, rounded once to f32 (the scalar path searches in the projected space).
+    std::vector<float> P((size_t)c->K * M);
+    for (uint32_t k = 0; k < c->K; ++k)
+        for (uint32_t m = 0; m < M; ++m) {
+            double t = 0.0;
+            for (uint32_t d = 0; d < D; ++d) t += (double)Om[(size_t)m * D + d] * (double)c->hW[(size_t)k * D + d];
+            P[(size_t)k * M + m] = (float)t;
+        }
+    return upload(c, &c->dP, P.data(), P.size());
+}
+
+int vqhip_set_local_omegas(vqhip_ctx *c, const float *Oms, uint32_t K, uint32_t M, uint32_t D)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "set_local_omegas before set_prototypes");
+    HIPCHK(c, hipSetDevice(c->device));
+    drop_engine(c);
+    free_omega(c);
+    if (!Oms) return VQHIP_OK;
+    if (M == 0 || D != c->D || K != c->K)
+        return c->fail(VQHIP_ERR_INVALID, "set_local_omegas: M is 0 or K/D differ from the prototypes");
+    c->hOm.assign(Oms, Oms + (size_t)K * M * D);
+    c->M = M;
+    c->omega_kind = OMEGA_LOCAL;
+    return upload(c, &c->dOm, Oms, (size_t)K * M * D);
+}
+
+int vqhip_set_kernel_policy(vqhip_ctx *c, int policy)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (policy < VQHIP_KERNEL_AUTO || policy > VQHIP_KERNEL_MFMA) return c->fail(VQHIP_ERR_INVALID, "unknown kernel policy");
+    c->policy = policy;
+    return VQHIP_OK;
+}
+
+int vqhip_assign(vqhip_ctx *c, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && !idx_out) return c->fail(VQHIP_ERR_INVALID, "assign: idx_out is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_host(c, X, nullptr, N, idx_out, dist_out, nullptr, nullptr);
+}
+
+int vqhip_assign_device(vqhip_ctx *c, const float *dX, uint64_t N, uint32_t *didx_out, float *ddist_out, void *stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!dX || !didx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_device: dX or didx_out is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_device(c, dX, N, nullptr, Outputs{didx_out, ddist_out, nullptr, nullptr}, (hipStream_t)stream);
+}
+
+int vqhip_assign_matched(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, uint32_t *jpos, float *dpos,
+                         uint32_t *jneg, float *dneg)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && !y) return c->fail(VQHIP_ERR_INVALID, "assign_matched: y is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_host(c, X, y, N, jpos, dpos, jneg, dneg);
+}
+
+int vqhip_assign_matched_device(vqhip_ctx *c, const float *dX, const uint32_t *dy, uint64_t N, uint32_t *djpos,
+                                float *ddpos, uint32_t *djneg, float *ddneg, void *stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!dX || !dy)) return c->fail(VQHIP_ERR_INVALID, "assign_matched_device: dX or dy is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_device(c, dX, N, dy, Outputs{djpos, ddpos, djneg, ddneg}, (hipStream_t)stream);
+}
+
+int vqhip_synth_fill_device(vqhip_ctx *c, float *dout, uint64_t count, uint64_t first, uint64_t seed,
+                            uint32_t stream_id, float scale, const float *dbase, uint64_t base_len, void *stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if ((count && !dout) || (dbase && base_len == 0)) return c->fail(VQHIP_ERR_INVALID, "synth_fill_device: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, launch_synth_fill(dout, count, first, seed, stream_id, scale, dbase, base_len, (hipStream_t)stream));
+    return VQHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Internal declarations shared by the translation units of libvqhip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/vqhip.h"
+
+namespace vq {
+
+// ---------------------------------------------------------------- synthetic values
+// value(seed, stream, i): SplitMix64 of a per-(seed, stream) key plus the counter; the top
+// 24 bits become an f32 in [-1, 1).  Identical on host and device (integer ops + one exact
+// int->float conversion + exact scaling).
+__host__ __device__ inline uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline uint64_t synth_key(uint64_t seed, uint32_t stream)
+{
+    return splitmix64(seed ^ (0xA0761D6478BD642Full * (uint64_t)(stream + 1u)));
+}
+__host__ __device__ inline float synth_value(uint64_t key, uint64_t i)
+{
+    uint32_t top = (uint32_t)(splitmix64(key + i) >> 40);          // 24 bits
+    return (float)(int32_t)top * (1.0f / 8388608.0f) - 1.0f;       // exact: [0,2^24) * 2^-23 - 1
+}
+
+// ---------------------------------------------------------------- model as kernels see it
+enum OmegaKind : int { OMEGA_NONE = 0, OMEGA_GLOBAL = 1, OMEGA_LOCAL = 2 };
+
+struct Outputs {           // any pointer may be null
+    uint32_t *idx;  float *dist;       // plain search, or the matching search
+    uint32_t *jneg; float *dneg;       // non-matching search (matched calls only)
+};
+
+// ---------------------------------------------------------------- scalar kernels (kernels_scalar.hip)
+// X: N x D (ld = D).  Direct (x-w)^2 form, sums in index order, strict '<' from (0, +INF).
+hipError_t launch_assign_scalar(const float *dX, uint64_t N, uint32_t D, const float *dW, uint32_t K,
+                                const uint32_t *dcls, const uint32_t *dy, bool rooted, Outputs out,
+                                hipStream_t s);
+// Y[i][m] = sum_d Om[m][d] * X[i][d]
+hipError_t launch_project_scalar(const float *dX, uint64_t N, uint32_t D, const float *dOm, uint32_t M,
+                                 float *dY, hipStream_t s);
+// dist_j = sum_m ( sum_d Om_j[m][d] * (x[d] - w_j[d]) )^2
+hipError_t launch_assign_local_scalar(const float *dX, uint64_t N, uint32_t D, const float *dW, uint32_t K,
+                                      const float *dOms, uint32_t M, const uint32_t *dcls,
+                                      const uint32_t *dy, Outputs out, hipStream_t s);
+
+// ---------------------------------------------------------------- MFMA engine (kernels_mfma.hip)
+struct EngineModel;   // device tile images + shapes, built by the engine from host copies
+
+// Returns nullptr (and sets why) when the shape is not eligible for the engine.
+EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, const std::vector<float> &Om,
+                          int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, std::string &why,
+                          hipError_t &herr);
+void engine_free(EngineModel *m);
+const char *engine_name(const EngineModel *m);
+hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out,
+                         hipStream_t s);
+
+// ---------------------------------------------------------------- synth (synth.hip)
+hipError_t launch_synth_fill(float *dout, uint64_t count, uint64_t first, uint64_t seed, uint32_t stream_id,
+                             float scale, const float *dbase, uint64_t base_len, hipStream_t s);
+
+}  // namespace vq
