@@ -92,6 +92,20 @@ SHAPES = [
 ]
 
 
+# kernel family VQHIP_KERNEL_AUTO must pick per shape (the engine serves D % 4 == 0, D <= 256)
+AUTO_KERNEL = {
+    "c1_vq_iris_shape": "mfma_euclid", "glvq_128x256": "mfma_euclid", "glvq_ragged_d100_k37": "mfma_euclid",
+    "glvq_d64_k70": "mfma_euclid", "gmlvq_128x128": "mfma_omega", "gmlvq_small_d12": "mfma_omega",
+    "liramlvq_r16_d256": "mfma_omega", "liramlvq_r3_d20": "mfma_omega", "lgmlvq_8x128": "mfma_local",
+    "lgmlvq_small": "scalar",      # D = 10 is not a multiple of 4
+}
+
+
+def _expect_kernel(ctx, shape, policy):
+    want = "scalar" if policy == KERNEL_SCALAR else AUTO_KERNEL[shape[0]]
+    assert ctx.last_kernel == want, f"{shape[0]}: ran {ctx.last_kernel}, expected {want}"
+
+
 def _model(shape):
     name, model, N, D, K, M, om = shape
     return synth.make_model(synth.Config(name, model, N, D, K, M=M, omega=om, classes=min(8, max(2, K // 2))))
@@ -115,6 +129,7 @@ def test_predict_parity(ctx, shape, policy):
     rep = parity.compare(idx, dist, o_idx, o_best, o_second, atol=_atol(m))
     print(shape[0], ctx.last_kernel, rep)
     assert rep.ok, str(rep)
+    _expect_kernel(ctx, shape, policy)
     # structured data: sample i was drawn around prototype i mod K (not guaranteed for Omega models)
     if m.cfg.omega == "none" and m.cfg.D >= 32:
         assert (idx == np.arange(m.cfg.N) % m.cfg.K).all()
@@ -135,6 +150,7 @@ def test_matched_parity(ctx, shape, policy):
         rep = parity.compare(j, d, *o, atol=_atol(m))
         print(shape[0], "matching" if matching else "non-matching", ctx.last_kernel, rep)
         assert rep.ok, str(rep)
+    _expect_kernel(ctx, shape, policy)
 
 
 def test_unstructured_data_parity(ctx):

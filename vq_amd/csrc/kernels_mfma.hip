@@ -1,23 +1,667 @@
-// MFMA engine -- placeholder until the tile kernels land: reports "not eligible" so that
-// VQHIP_KERNEL_AUTO uses the scalar kernels and VQHIP_KERNEL_MFMA fails loudly.
+// MFMA tile engine for gfx950: nearest-prototype search as streamed-weight f32 MFMA GEMMs.
+// Geometry and the reasons behind it: engine.h.  What each kernel restates:
+//
+//   k_engine<MODE_EUCLID>  find_closest_prototype{,_matched}, omega = None     src/helpers.rs:55-77, 91-132
+//        screening score_k = ||w_k||^2 - 2 x.w_k on the matrix cores (argmin-equivalent to
+//        helpers.rs:11-24), best TWO candidates per sample re-measured in the direct
+//        sum (x_d - w_kd)^2 form, rooted, compared like helpers.rs:70.
+//   k_engine<MODE_OMEGA>   the same with Some(omega): y = Omega x on the matrix cores, then the
+//        Euclidean machinery in the projected space against p_k = Omega w_k; distance
+//        ||y - p_k||^2 = (x-w)^T Omega^T Omega (x-w), squared                  src/helpers.rs:35-45
+//   k_engine<MODE_LOCAL>   LGMLVQ: z = Omega_j x - Omega_j w_j per prototype j, ||z||^2,
+//        strict '<' in index order                                             src/lgmlvq/lgmlvq.rs:436-506
+//
+// One workgroup = 4 waves; each wave keeps S tiles of 32 samples in registers and all waves walk
+// the same stream of weight-tile groups through a double-buffered LDS stage filled by LDS-DMA
+// (global_load_lds_dwordx4), one barrier per group.
+#include <cmath>
+#include <cstring>
+#include <type_traits>
+
+#include "engine.h"
 #include "vq_common.h"
 
 namespace vq {
 
-struct EngineModel {};
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-EngineModel *engine_build(const std::vector<float> &, uint32_t, uint32_t, const std::vector<float> &, int, uint32_t,
-                          const std::vector<uint32_t> &, std::string &why, hipError_t &herr)
+enum { MODE_EUCLID = 0, MODE_OMEGA = 1, MODE_LOCAL = 2 };
+
+struct EngineArgs {
+    const float *X;           // N x D samples (row stride D)
+    uint64_t N;
+    uint32_t D;               // actual sample length (multiple of 4, <= R1)
+    const uint32_t *y;        // sample class ids (matched) or null
+    const float *img1;        // stage-1 groups: prototypes (EUCLID), Omega rows (OMEGA), Omega_j rows (LOCAL)
+    uint32_t ngroups1;
+    const float *img2;        // stage-2 groups: projected prototypes (OMEGA)
+    uint32_t ngroups2;
+    const float *plain;       // K x ldp rows for the exact re-measurement (W, or P = W.Omega^T), zero padded
+    uint32_t ldp;
+    uint32_t K;               // actual number of prototypes
+    uint32_t tiles_per_proto; // LOCAL: 32-row tiles per Omega_j
+    uint64_t nbatches;
+    Outputs out;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ uint32_t xor32(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 32, 64); }
+
+__device__ __forceinline__ bool lexless(float av, uint32_t ai, float bv, uint32_t bi)
+{
+    return av < bv || (av == bv && ai < bi);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Running best two (value, index) of a lane.  Offers arrive with increasing index, so strict '<'
+// keeps the lower index on ties (helpers.rs:70); NaN never enters.
+struct Top2 {
+    float b1, b2;
+    uint32_t i1, i2;
+    __device__ Top2() : b1(INFINITY), b2(INFINITY), i1(0u), i2(0u) {}
+    __device__ __forceinline__ void offer(float v, uint32_t k)
+    {
+        const bool c1 = v < b1, c2 = v < b2;
+        b2 = c1 ? b1 : (c2 ? v : b2);
+        i2 = c1 ? i1 : (c2 ? k : i2);
+        b1 = c1 ? v : b1;
+        i1 = c1 ? k : i1;
+    }
+    // union with the partner lane's pair (the other 16 rows of every tile)
+    __device__ __forceinline__ void merge_halves()
+    {
+        const float o1 = xor32(b1), o2 = xor32(b2);
+        const uint32_t oi1 = xor32(i1), oi2 = xor32(i2);
+        float f, s;
+        uint32_t fi, si;
+        if (lexless(o1, oi1, b1, i1)) {
+            f = o1; fi = oi1;
+            if (lexless(b1, i1, o2, oi2)) { s = b1; si = i1; } else { s = o2; si = oi2; }
+        } else {
+            f = b1; fi = i1;
+            if (lexless(o1, oi1, b2, i2)) { s = o1; si = oi1; } else { s = b2; si = i2; }
+        }
+        b1 = f; i1 = fi; b2 = s; i2 = si;
+    }
+};
+
+struct Best1 {
+    float d;
+    uint32_t i;
+    __device__ Best1() : d(INFINITY), i(0u) {}                          // helpers.rs:58-59
+    __device__ __forceinline__ void offer(float v, uint32_t k)
+    {
+        const bool c = v < d;                                            // helpers.rs:70
+        d = c ? v : d;
+        i = c ? k : i;
+    }
+    __device__ __forceinline__ void merge_halves()
+    {
+        const float o = xor32(d);
+        const uint32_t oi = xor32(i);
+        if (lexless(o, oi, d, i)) { d = o; i = oi; }
+    }
+};
+
+// LDS-DMA of one stage (BYTES, multiple of 16) from its pre-swizzled global image: a linear copy,
+// 1 KiB per wave-instruction, pieces dealt round-robin to the 4 waves.
+template <int BYTES>
+__device__ __forceinline__ void stage_group(char *lds_dst, const char *gsrc, int wave, int lane)
+{
+    constexpr int PIECES = (BYTES + 1023) / 1024;
+#pragma unroll
+    for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+        const int p = i * 4 + wave;
+        const int off = p * 1024 + lane * 16;
+        if (p < PIECES && off < BYTES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + off),
+                                             (__attribute__((address_space(3))) void *)(lds_dst + p * 1024), 16, 0, 0);
+    }
+}
+
+// acc[s] (+)= tile . xf[s]^T for one 32-row tile in LDS; accumulators start at the tile's init column.
+template <int R, int S>
+__device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S][R / 8], f32x16 (&acc)[S], int row, int h)
+{
+    using Gm = Geom<R>;
+    const float *tail = tile + Gm::W_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
+            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
+        }
+    }
+    const int sw = Gm::swz(row);
+    const float *rowp = tile + row * R;
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 a = *(const f32x4 *)(rowp + (((2 * j + h) ^ sw) << 2));
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], xf[s][j][e], acc[s], 0, 0, 0);
+    }
+}
+
+// Exact distance of one sample (fragment xf, this lane's half of the chunks) to row `k` of the
+// zero-padded plain matrix: sum over the lane's chunks, then both halves added.
+template <int R>
+__device__ __forceinline__ float exact_sq(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t k, int h)
+{
+    const float *w = plain + (size_t)k * ldp;
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 wv = *(const f32x4 *)(w + 4 * (2 * j + h));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = wv[e] - xf[j][e];
+            p = fmaf(d, d, p);
+        }
+    }
+    return p + xor32(p);
+}
+
+// Full exact scan in index order (helpers.rs:55-77 in f32): used only when the screening scores of
+// a sample are unusable (-INF from an infinite input, or a non-finite re-measured winner).
+template <int R, bool ROOT>
+__device__ __noinline__ void exact_scan(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t K, int h,
+                                        const uint32_t *cls_plain, bool matched, uint32_t label, Best1 &pos, Best1 &neg)
+{
+    pos = Best1();
+    neg = Best1();
+    for (uint32_t k = 0; k < K; ++k) {
+        float d = exact_sq<R>(xf, plain, ldp, k, h);
+        if (ROOT) d = sqrtf(d);
+        if (!matched || cls_plain[k] == label) pos.offer(d, k);
+        else neg.offer(d, k);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ the kernel
+// R1: padded sample length.  R2: padded projected length (OMEGA only).  S: sample tiles per wave.
+template <int MODE, int R1, int R2, int S, bool MATCHED>
+__global__ void __launch_bounds__(256, (R1 >= 256 ? 1 : 2)) k_engine(const EngineArgs a, const uint32_t *__restrict__ cls_plain)
+{
+    using G1 = Geom<R1>;
+    using G2 = Geom<MODE == MODE_OMEGA ? R2 : R1>;
+    constexpr int RS = MODE == MODE_OMEGA ? R2 : R1;                 // reduction length of the search stage
+    constexpr int BUF_BYTES = G1::STAGE_BYTES > G2::STAGE_BYTES ? G1::STAGE_BYTES : G2::STAGE_BYTES;
+    constexpr bool ROOT = MODE == MODE_EUCLID;                       // helpers.rs:23 vs :44
+    // OMEGA: Omega is zero padded to max(32, R2) rows, so the projection stages are known at compile time
+    constexpr int T1 = R2 >= 32 ? R2 / 32 : 1;
+    constexpr int NG1 = (T1 + G1::G - 1) / G1::G;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ngroups = MODE == MODE_OMEGA ? NG1 + a.ngroups2 : a.ngroups1;
+    const uint32_t Cact = a.D >> 2;
+
+    // DMA source of stage q of the cyclic weight stream
+    auto issue = [&](uint32_t q, int buf) {
+        char *dst = smem + buf * BUF_BYTES;
+        if (MODE == MODE_OMEGA && q >= (uint32_t)NG1)
+            stage_group<G2::STAGE_BYTES>(dst, (const char *)(a.img2 + (size_t)(q - NG1) * G2::STAGE_FLOATS), wave, lane);
+        else
+            stage_group<G1::STAGE_BYTES>(dst, (const char *)(a.img1 + (size_t)q * G1::STAGE_FLOATS), wave, lane);
+    };
+
+    int cur = 0;
+    if ((uint64_t)blockIdx.x < a.nbatches) {
+        issue(0, 0);
+        __syncthreads();                                             // waits vmcnt(0) for the DMA, then barrier
+    }
+
+    for (uint64_t b = blockIdx.x; b < a.nbatches; b += gridDim.x) {
+        const bool last_batch = b + gridDim.x >= a.nbatches;
+
+        // ---- this wave's S tiles of 32 samples -> B fragments (straight from HBM, 16 B per lane)
+        f32x4 xf[S][R1 / 8];
+        uint64_t sample[S];
+        uint32_t label[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sample[s] = ((b * 4 + wave) * S + s) * 32 + s_col;
+            const bool live = sample[s] < a.N;
+            const float *xrow = a.X + sample[s] * a.D;
+#pragma unroll
+            for (int j = 0; j < R1 / 8; ++j) {
+                const uint32_t c = 2 * j + h;
+                xf[s][j] = (live && c < Cact) ? *(const f32x4 *)(xrow + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            label[s] = (MATCHED && live) ? a.y[sample[s]] : 0u;
+        }
+
+        f32x4 yf[S][RS / 8];                                          // search-stage fragments
+        Top2 top[S];
+        Best1 pos[S], neg[S];
+        float dsum[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) dsum[s] = 0.0f;
+        if (MODE != MODE_OMEGA) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int j = 0; j < RS / 8; ++j) yf[s][j] = xf[s][j < R1 / 8 ? j : 0];
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int j = 0; j < RS / 8; ++j) yf[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+        // One step of the cyclic weight stream: prefetch the next stage, compute on this one, barrier.
+        uint32_t q = 0;
+        auto step = [&](auto &&compute) {
+            if (!(last_batch && q + 1 == ngroups)) issue(q + 1 == ngroups ? 0u : q + 1, cur ^ 1);
+            compute((const float *)(smem + cur * BUF_BYTES));
+            __syncthreads();            // next stage landed (vmcnt(0)) and everyone is done reading this one
+            cur ^= 1;
+            ++q;
+        };
+
+        if constexpr (MODE == MODE_OMEGA) {
+            // ---- projection: y = Omega x; accumulator registers become the search stage's fragment:
+            //      row 8g + 4h + e of Omega tile t  ==  element e of chunk 2(4t + g) + h of y
+            static_for<0, NG1>([&](auto q1) {
+                step([&](const float *stage) {
+                    static_for<0, G1::G>([&](auto tt) {
+                        constexpr int t = decltype(q1)::value * G1::G + decltype(tt)::value;
+                        f32x16 acc[S];
+                        tile_mma<R1, S>(stage + decltype(tt)::value * G1::TILE_FLOATS, xf, acc, s_col, h);
+                        static_for<0, 4>([&](auto g) {
+                            constexpr int jj = 4 * t + decltype(g)::value;
+                            if constexpr (jj < RS / 8) {
+#pragma unroll
+                                for (int s = 0; s < S; ++s)
+                                    yf[s][jj] = f32x4{acc[s][4 * g], acc[s][4 * g + 1], acc[s][4 * g + 2], acc[s][4 * g + 3]};
+                            }
+                        });
+                    });
+                });
+            });
+        }
+
+        const uint32_t nsearch = MODE == MODE_OMEGA ? a.ngroups2 : a.ngroups1;
+        for (uint32_t qs = 0; qs < nsearch; ++qs) {
+            step([&](const float *stage) {
+                if constexpr (MODE == MODE_LOCAL) {
+                    // ---- z = Omega_j x - Omega_j w_j (accumulator starts at -p_j), ||z||^2 summed per prototype
+#pragma unroll
+                    for (int tt = 0; tt < G1::G; ++tt) {
+                        const float *tile = stage + tt * G1::TILE_FLOATS;
+                        f32x16 acc[S];
+                        tile_mma<R1, S>(tile, xf, acc, s_col, h);
+                        const uint32_t ti = qs * G1::G + tt;
+                        const uint32_t j = ti / a.tiles_per_proto, t = ti % a.tiles_per_proto;
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) dsum[s] = fmaf(acc[s][r], acc[s][r], dsum[s]);
+                        if (t + 1 == a.tiles_per_proto) {
+                            const uint32_t cj = ((const uint32_t *)(tile + G1::W_FLOATS))[32];
+#pragma unroll
+                            for (int s = 0; s < S; ++s) {
+                                const float total = dsum[s] + xor32(dsum[s]);
+                                dsum[s] = 0.0f;
+                                if (j < a.K) {                        // pad tiles past the last prototype never compete
+                                    if (!MATCHED || cj == label[s]) pos[s].offer(total, j);   // lgmlvq.rs:448 / :487
+                                    else neg[s].offer(total, j);                               // lgmlvq.rs:496
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // ---- search stage: score = ||p_k||^2 - 2 y.p_k for 32 prototypes per tile
+#pragma unroll
+                    for (int tt = 0; tt < G2::G; ++tt) {
+                        const float *tile = stage + tt * G2::TILE_FLOATS;
+                        f32x16 acc[S];
+                        tile_mma<RS, S>(tile, yf, acc, s_col, h);
+                        const uint32_t kbase = (qs * G2::G + tt) * 32 + 4 * h;
+                        const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            u32x4 cg;
+                            if (MATCHED) cg = *(const u32x4 *)(tcls + 8 * g + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t k = kbase + 8 * g + e;
+#pragma unroll
+                                for (int s = 0; s < S; ++s) {
+                                    const float v = acc[s][4 * g + e];
+                                    if (!MATCHED) top[s].offer(v, k);
+                                    else if (cg[e] == label[s]) pos[s].offer(v, k);       // helpers.rs:113
+                                    else neg[s].offer(v, k);                               // helpers.rs:122
+                                }
+                            }
+                        }
+                    }
+                }
+            });
+        }
+
+        // ---- epilogue: lane pair (s, h=0/1) agrees on the winner, re-measures it exactly, stores
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool live = sample[s] < a.N;
+            Best1 wp, wn;                                              // final (distance, index)
+            if (MODE == MODE_LOCAL) {
+                wp = pos[s];
+                wn = neg[s];
+            } else {
+                bool rescan = false;
+                if (!MATCHED) {
+                    top[s].merge_halves();
+                    const Top2 &t = top[s];
+                    if (t.b1 < INFINITY) {
+                        float d1 = exact_sq<RS>(yf[s], a.plain, a.ldp, t.i1, h);
+                        if (ROOT) d1 = sqrtf(d1);
+                        wp.d = d1; wp.i = t.i1;
+                        if (t.b2 < INFINITY) {
+                            float d2 = exact_sq<RS>(yf[s], a.plain, a.ldp, t.i2, h);
+                            if (ROOT) d2 = sqrtf(d2);
+                            if (lexless(d2, t.i2, d1, t.i1)) { wp.d = d2; wp.i = t.i2; }
+                        }
+                        rescan = t.b1 == -INFINITY || !(wp.d < INFINITY);
+                    }
+                } else {
+                    pos[s].merge_halves();
+                    neg[s].merge_halves();
+                    if (pos[s].d < INFINITY) {
+                        float d = exact_sq<RS>(yf[s], a.plain, a.ldp, pos[s].i, h);
+                        wp.d = ROOT ? sqrtf(d) : d; wp.i = pos[s].i;
+                        rescan |= pos[s].d == -INFINITY || !(wp.d < INFINITY);
+                    }
+                    if (neg[s].d < INFINITY) {
+                        float d = exact_sq<RS>(yf[s], a.plain, a.ldp, neg[s].i, h);
+                        wn.d = ROOT ? sqrtf(d) : d; wn.i = neg[s].i;
+                        rescan |= neg[s].d == -INFINITY || !(wn.d < INFINITY);
+                    }
+                }
+                if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, cls_plain, MATCHED, label[s], wp, wn);
+            }
+            if (live) {
+                if (h == 0) {
+                    if (a.out.idx) a.out.idx[sample[s]] = wp.i;
+                    if (MATCHED && a.out.jneg) a.out.jneg[sample[s]] = wn.i;
+                } else {
+                    if (a.out.dist) a.out.dist[sample[s]] = wp.d;
+                    if (MATCHED && a.out.dneg) a.out.dneg[sample[s]] = wn.d;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+struct EngineModel {
+    int mode = MODE_EUCLID;
+    uint32_t K = 0, D = 0, M = 0, R1 = 0, R2 = 0, tiles_per_proto = 0;
+    bool has_cls = false;
+    float *img1 = nullptr, *img2 = nullptr, *plain = nullptr;
+    uint32_t *cls = nullptr;
+    uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
+    const char *name = "mfma";
+    hipError_t (*launch)(const EngineModel &, const EngineArgs &, bool matched, hipStream_t) = nullptr;
+    int samples_per_batch = 0;
+};
+
+namespace {
+
+int pad_pow2(uint32_t v, int lo)
+{
+    int r = lo;
+    while ((uint32_t)r < v) r <<= 1;
+    return r;
+}
+
+// Tile images for `nrows` weight rows of length `len` (zero padded to R), scaled by `scale`;
+// init[r] / cls[r] fill the tail; pad rows get (0 weights, pad_init, cls 0xFFFFFFFF).
+template <int R>
+std::vector<float> build_images(const float *rows, size_t nrows, size_t len, size_t ld, float scale, const float *init,
+                                const uint32_t *cls, float pad_init, uint32_t &ngroups, size_t min_rows = 0)
+{
+    using Gm = Geom<R>;
+    const size_t tiles = ((nrows > min_rows ? nrows : min_rows) + 31) / 32;
+    ngroups = (uint32_t)((tiles + Gm::G - 1) / Gm::G);
+    std::vector<float> img((size_t)ngroups * Gm::STAGE_FLOATS, 0.0f);
+    for (size_t t = 0; t < (size_t)ngroups * Gm::G; ++t) {
+        float *tile = img.data() + t * Gm::TILE_FLOATS;
+        float *tail = tile + Gm::W_FLOATS;
+        for (int r = 0; r < 32; ++r) {
+            const size_t gr = t * 32 + r;
+            uint32_t c = 0xFFFFFFFFu;
+            if (gr < nrows) {
+                for (size_t d = 0; d < len; ++d)
+                    tile[Gm::chunk_off(r, (int)(d >> 2)) + (d & 3)] = scale * rows[gr * ld + d];
+                tail[r] = init ? init[gr] : 0.0f;
+                if (cls) c = cls[gr];
+            } else {
+                tail[r] = pad_init;
+            }
+            std::memcpy(&tail[32 + r], &c, 4);
+        }
+    }
+    return img;
+}
+
+template <class T>
+hipError_t to_device(T **dst, const std::vector<T> &src)
+{
+    hipError_t e = hipMalloc((void **)dst, src.size() * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+template <int MODE, int R1, int R2, int S>
+hipError_t launch_t(const EngineModel &m, const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t cap = 256ull * (R1 >= 256 ? 1ull : 2ull);          // 256 CUs x workgroups per CU
+    const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
+    if (matched)
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true>), dim3(grid), dim3(256), 0, st, a, m.cls);
+    else
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false>), dim3(grid), dim3(256), 0, st, a, m.cls);
+    return hipGetLastError();
+}
+
+template <int MODE, int R1, int R2, int S>
+void bind(EngineModel &m)
+{
+    m.launch = &launch_t<MODE, R1, R2, S>;
+    m.samples_per_batch = 4 * S * 32;
+}
+
+template <int R1>
+bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<float> &W, const std::vector<float> &norms,
+                 const std::vector<uint32_t> &cls)
+{
+    if (m.R1 != (uint32_t)R1) return false;
+    img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
+                           m.ngroups1);
+    bind<MODE_EUCLID, R1, R1, (R1 >= 256 ? 1 : 2)>(m);
+    return true;
+}
+
+template <int R1, int R2>
+bool bind_omega(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
+                const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
+{
+    if (m.R1 != (uint32_t)R1 || m.R2 != (uint32_t)R2) return false;
+    img1 = build_images<R1>(Om.data(), m.M, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, m.ngroups1, R2 >= 32 ? R2 : 32);
+    img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
+                            m.ngroups2);
+    bind<MODE_OMEGA, R1, R2, 1>(m);
+    return true;
+}
+
+template <int R1>
+bool bind_local(EngineModel &m, std::vector<float> &img, const std::vector<float> &Oms, const std::vector<float> &negp,
+                const std::vector<uint32_t> &cls)
+{
+    if (m.R1 != (uint32_t)R1) return false;
+    // every Omega_j padded to whole 32-row tiles, so a tile never straddles two prototypes
+    const uint32_t tpp = (m.M + 31) / 32, rows_pp = tpp * 32;
+    std::vector<float> rows((size_t)m.K * rows_pp * m.D, 0.0f), init((size_t)m.K * rows_pp, 0.0f);
+    std::vector<uint32_t> rcls((size_t)m.K * rows_pp, 0xFFFFFFFFu);
+    for (uint32_t j = 0; j < m.K; ++j)
+        for (uint32_t r = 0; r < rows_pp; ++r) {
+            const size_t o = (size_t)j * rows_pp + r;
+            if (r < m.M) {
+                std::memcpy(&rows[o * m.D], &Oms[((size_t)j * m.M + r) * m.D], m.D * sizeof(float));
+                init[o] = negp[(size_t)j * m.M + r];
+            }
+            if (!cls.empty()) rcls[o] = cls[j];
+        }
+    img = build_images<R1>(rows.data(), rows.size() / m.D, m.D, m.D, 1.0f, init.data(), rcls.data(), 0.0f, m.ngroups1);
+    m.tiles_per_proto = tpp;
+    bind<MODE_LOCAL, R1, R1, (R1 >= 256 ? 1 : 2)>(m);
+    return true;
+}
+
+}  // namespace
+
+EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, const std::vector<float> &Om,
+                          int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, std::string &why,
+                          hipError_t &herr)
 {
     herr = hipSuccess;
-    why = "engine not implemented yet";
-    return nullptr;
+    if (D % 4 != 0 || D > 256) {
+        why = "sample length must be a multiple of 4 and at most 256";
+        return nullptr;
+    }
+    if (omega_kind != OMEGA_NONE && M > 256) {
+        why = "Omega has more than 256 rows";
+        return nullptr;
+    }
+    EngineModel m;
+    m.K = K; m.D = D; m.M = M;
+    m.R1 = (uint32_t)pad_pow2(D, 16);
+    m.has_cls = !cls.empty();
+    std::vector<float> img1, img2, plain;
+    bool ok = false;
+
+    if (omega_kind == OMEGA_NONE || omega_kind == OMEGA_GLOBAL) {
+        // search space: the prototypes themselves, or their projections p_k = Omega w_k (f64, rounded once)
+        const uint32_t L = omega_kind == OMEGA_NONE ? D : M;
+        std::vector<float> P;
+        if (omega_kind == OMEGA_GLOBAL) {
+            P.resize((size_t)K * M);
+            for (uint32_t k = 0; k < K; ++k)
+                for (uint32_t r = 0; r < M; ++r) {
+                    double t = 0.0;
+                    for (uint32_t d = 0; d < D; ++d) t += (double)Om[(size_t)r * D + d] * (double)W[(size_t)k * D + d];
+                    P[(size_t)k * M + r] = (float)t;
+                }
+        }
+        const std::vector<float> &Q = omega_kind == OMEGA_NONE ? W : P;
+        std::vector<float> norms(K);
+        for (uint32_t k = 0; k < K; ++k) {
+            double t = 0.0;
+            for (uint32_t d = 0; d < L; ++d) t += (double)Q[(size_t)k * L + d] * (double)Q[(size_t)k * L + d];
+            norms[k] = (float)t;
+            // The screening form needs ||p||^2 and 2 p.x inside f32 range; the scalar kernels do not.
+            if (!(t < 1e37)) {
+                why = "a prototype's squared norm is not finite in f32";
+                return nullptr;
+            }
+        }
+        if (omega_kind == OMEGA_NONE) {
+            m.mode = MODE_EUCLID;
+            m.name = "mfma_euclid";
+            m.ldp = m.R1;
+            ok = bind_euclid<16>(m, img1, W, norms, cls) || bind_euclid<32>(m, img1, W, norms, cls) ||
+                 bind_euclid<64>(m, img1, W, norms, cls) || bind_euclid<128>(m, img1, W, norms, cls) ||
+                 bind_euclid<256>(m, img1, W, norms, cls);
+        } else {
+            m.mode = MODE_OMEGA;
+            m.name = "mfma_omega";
+            m.R2 = (uint32_t)pad_pow2(M, 16);
+            m.ldp = m.R2;
+            ok = bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<16, 16>(m, img1, img2, Om, P, norms, cls) || bind_omega<32, 16>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<32, 32>(m, img1, img2, Om, P, norms, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, norms, cls);
+        }
+        // zero-padded plain rows for the exact re-measurement
+        plain.assign((size_t)K * m.ldp, 0.0f);
+        for (uint32_t k = 0; k < K; ++k) std::memcpy(&plain[(size_t)k * m.ldp], &Q[(size_t)k * L], L * sizeof(float));
+    } else {
+        m.mode = MODE_LOCAL;
+        m.name = "mfma_local";
+        std::vector<float> negp((size_t)K * M);                        // -Omega_j w_j (f64, rounded once)
+        for (uint32_t j = 0; j < K; ++j)
+            for (uint32_t r = 0; r < M; ++r) {
+                double t = 0.0;
+                for (uint32_t d = 0; d < D; ++d)
+                    t += (double)Om[((size_t)j * M + r) * D + d] * (double)W[(size_t)j * D + d];
+                negp[(size_t)j * M + r] = (float)(-t);
+            }
+        ok = bind_local<16>(m, img1, Om, negp, cls) || bind_local<32>(m, img1, Om, negp, cls) ||
+             bind_local<64>(m, img1, Om, negp, cls) || bind_local<128>(m, img1, Om, negp, cls) ||
+             bind_local<256>(m, img1, Om, negp, cls);
+    }
+    if (!ok) {
+        why = "no engine instantiation for this (D, M) pair";
+        return nullptr;
+    }
+
+    EngineModel *out = new EngineModel(m);
+    herr = to_device(&out->img1, img1);
+    if (herr == hipSuccess && !img2.empty()) herr = to_device(&out->img2, img2);
+    if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
+    if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
+    if (herr != hipSuccess) {
+        engine_free(out);
+        return nullptr;
+    }
+    return out;
 }
-void engine_free(EngineModel *m) { delete m; }
-const char *engine_name(const EngineModel *) { return "mfma"; }
-hipError_t engine_assign(const EngineModel *, const float *, uint64_t, const uint32_t *, Outputs, hipStream_t)
+
+void engine_free(EngineModel *m)
 {
-    return hipErrorNotSupported;
+    if (!m) return;
+    (void)hipFree(m->img1);
+    (void)hipFree(m->img2);
+    (void)hipFree(m->plain);
+    (void)hipFree(m->cls);
+    delete m;
+}
+
+const char *engine_name(const EngineModel *m) { return m->name; }
+
+hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s)
+{
+    if (N == 0) return hipSuccess;
+    EngineArgs a;
+    a.X = dX; a.N = N; a.D = m->D; a.y = dy;
+    a.img1 = m->img1; a.ngroups1 = m->ngroups1;
+    a.img2 = m->img2; a.ngroups2 = m->ngroups2;
+    a.plain = m->plain; a.ldp = m->ldp;
+    a.K = m->K; a.tiles_per_proto = m->tiles_per_proto;
+    a.nbatches = (N + m->samples_per_batch - 1) / m->samples_per_batch;
+    a.out = out;
+    return m->launch(*m, a, dy != nullptr, s);
 }
 
 }  // namespace vq
