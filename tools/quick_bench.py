@@ -1,5 +1,6 @@
 """Scratch timing script (not part of the contract): python tools_quick_bench.py c2 [N]"""
-import sys, time
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from vq_amd import Context, synth
 name = sys.argv[1] if len(sys.argv) > 1 else "c2"

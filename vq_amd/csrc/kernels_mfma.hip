@@ -182,7 +182,7 @@ __device__ __forceinline__ float exact_sq(const f32x4 (&xf)[R / 8], const float 
 // Full exact scan in index order (helpers.rs:55-77 in f32): used only when the screening scores of
 // a sample are unusable (-INF from an infinite input, or a non-finite re-measured winner).
 template <int R, bool ROOT>
-__device__ __noinline__ void exact_scan(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t K, int h,
+__device__ __forceinline__ void exact_scan(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t K, int h,
                                         const uint32_t *cls_plain, bool matched, uint32_t label, Best1 &pos, Best1 &neg)
 {
     pos = Best1();
