@@ -15,6 +15,7 @@
 // the same stream of weight-tile groups through a double-buffered LDS stage filled by LDS-DMA
 // (global_load_lds_dwordx4), one barrier per group.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -199,8 +200,8 @@ __device__ __forceinline__ void exact_scan(const f32x4 (&xf)[R / 8], const float
 
 // ------------------------------------------------------------------------------ the kernel
 // R1: padded sample length.  R2: padded projected length (OMEGA only).  S: sample tiles per wave.
-template <int MODE, int R1, int R2, int S, bool MATCHED>
-__global__ void __launch_bounds__(256, (R1 >= 256 ? 1 : 2)) k_engine(const EngineArgs a, const uint32_t *__restrict__ cls_plain)
+template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, int ABL = 0>
+__global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const uint32_t *__restrict__ cls_plain)
 {
     using G1 = Geom<R1>;
     using G2 = Geom<MODE == MODE_OMEGA ? R2 : R1>;
@@ -247,7 +248,9 @@ __global__ void __launch_bounds__(256, (R1 >= 256 ? 1 : 2)) k_engine(const Engin
 #pragma unroll
             for (int j = 0; j < R1 / 8; ++j) {
                 const uint32_t c = 2 * j + h;
-                xf[s][j] = (live && c < Cact) ? *(const f32x4 *)(xrow + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const bool ok = live && c < Cact;                 // load unconditionally from a safe address
+                const f32x4 v = *(const f32x4 *)(ok ? xrow + 4 * c : a.X);
+                xf[s][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             label[s] = (MATCHED && live) ? a.y[sample[s]] : 0u;
         }
@@ -273,9 +276,9 @@ __global__ void __launch_bounds__(256, (R1 >= 256 ? 1 : 2)) k_engine(const Engin
         // One step of the cyclic weight stream: prefetch the next stage, compute on this one, barrier.
         uint32_t q = 0;
         auto step = [&](auto &&compute) {
-            if (!(last_batch && q + 1 == ngroups)) issue(q + 1 == ngroups ? 0u : q + 1, cur ^ 1);
-            compute((const float *)(smem + cur * BUF_BYTES));
-            __syncthreads();            // next stage landed (vmcnt(0)) and everyone is done reading this one
+            if (!(ABL & 2) && !(last_batch && q + 1 == ngroups)) issue(q + 1 == ngroups ? 0u : q + 1, cur ^ 1);
+            compute((const float *)(smem + ((ABL & 2) ? 0 : cur) * BUF_BYTES));
+            if (!(ABL & 2)) __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading this one
             cur ^= 1;
             ++q;
         };
@@ -350,7 +353,8 @@ __global__ void __launch_bounds__(256, (R1 >= 256 ? 1 : 2)) k_engine(const Engin
 #pragma unroll
                                 for (int s = 0; s < S; ++s) {
                                     const float v = acc[s][4 * g + e];
-                                    if (!MATCHED) top[s].offer(v, k);
+                                    if (ABL & 1) top[s].b1 = fminf(top[s].b1, v);      // timing experiment only
+                                    else if (!MATCHED) top[s].offer(v, k);
                                     else if (cg[e] == label[s]) pos[s].offer(v, k);       // helpers.rs:113
                                     else neg[s].offer(v, k);                               // helpers.rs:122
                                 }
@@ -474,23 +478,31 @@ hipError_t to_device(T **dst, const std::vector<T> &src)
     return hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
-template <int MODE, int R1, int R2, int S>
+// WPS = workgroups per CU = waves per SIMD the register budget is cut for (256-thread workgroups).
+template <int MODE, int R1, int R2, int S, int WPS, int ABL = 0>
 hipError_t launch_t(const EngineModel &m, const EngineArgs &a, bool matched, hipStream_t st)
 {
-    const uint64_t cap = 256ull * (R1 >= 256 ? 1ull : 2ull);          // 256 CUs x workgroups per CU
+    uint64_t cap = 256ull * WPS;                                      // 256 CUs x workgroups per CU
+    if (const char *g = getenv("VQHIP_GRID")) cap = (uint64_t)atoll(g);  // experiments only
     const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
     if (matched)
-        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true>), dim3(grid), dim3(256), 0, st, a, m.cls);
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS, ABL>), dim3(grid), dim3(256), 0, st, a, m.cls);
     else
-        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false>), dim3(grid), dim3(256), 0, st, a, m.cls);
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false, WPS, ABL>), dim3(grid), dim3(256), 0, st, a, m.cls);
     return hipGetLastError();
 }
 
-template <int MODE, int R1, int R2, int S>
+template <int MODE, int R1, int R2, int S, int WPS = (R1 >= 256 ? 1 : 2)>
 void bind(EngineModel &m)
 {
-    m.launch = &launch_t<MODE, R1, R2, S>;
+    m.launch = &launch_t<MODE, R1, R2, S, WPS>;
     m.samples_per_batch = 4 * S * 32;
+}
+
+int variant_env()
+{
+    const char *v = getenv("VQHIP_VARIANT");     // experiments only: picks among co-compiled tilings
+    return v ? atoi(v) : 0;
 }
 
 template <int R1>
@@ -501,6 +513,15 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
                            m.ngroups1);
     bind<MODE_EUCLID, R1, R1, (R1 >= 256 ? 1 : 2)>(m);
+    if constexpr (R1 == 128) {
+        const int v = variant_env();
+        if (v == 1) bind<MODE_EUCLID, R1, R1, 1, 3>(m);
+        if (v == 2) bind<MODE_EUCLID, R1, R1, 1, 4>(m);
+        if (v == 3) bind<MODE_EUCLID, R1, R1, 1, 2>(m);
+        if (v == 11) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 1>;   // ablations: wrong results, timing only
+        if (v == 12) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 2>;
+        if (v == 13) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 3>;
+    }
     return true;
 }
 
