@@ -103,7 +103,7 @@ AUTO_KERNEL = {
 
 def _expect_kernel(ctx, shape, policy):
     want = "scalar" if policy == KERNEL_SCALAR else AUTO_KERNEL[shape[0]]
-    assert ctx.last_kernel == want, f"{shape[0]}: ran {ctx.last_kernel}, expected {want}"
+    assert ctx.last_kernel.startswith(want), f"{shape[0]}: ran {ctx.last_kernel}, expected {want}"
 
 
 def _model(shape):

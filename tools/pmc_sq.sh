@@ -8,11 +8,12 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ
 timeout -s KILL 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LEVEL_WAVES --output-format csv -d $OUT/sq2 -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --cpu-rows 0 > $OUT/sq2.log 2>&1 || { echo "sq2 failed"; tail -5 $OUT/sq2.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
+dur = 0
 for d in ("sq1", "sq2"):
     f = max(glob.glob("$OUT/%s/*/*counter_collection.csv" % d))
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_engine" in r["Kernel_Name"]:
+        if "k_engine" in r["Kernel_Name"] or "k_resident" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     for k, v in acc.items():

@@ -24,8 +24,8 @@ def counter(kind, name_part):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if name_part in r["Kernel_Name"]]
     return vals
 
-fetch = counter("pmc_fetch", "k_engine")
-write = counter("pmc_write", "k_engine")
+fetch = counter("pmc_fetch", "vq::k_")
+write = counter("pmc_write", "vq::k_")
 synth_w = counter("pmc_write", "k_synth_fill")
 out = {
     "workload": workload,

@@ -15,6 +15,7 @@
 // the same stream of weight-tile groups through a double-buffered LDS stage filled by LDS-DMA
 // (global_load_lds_dwordx4), one barrier per group.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -45,6 +46,9 @@ struct EngineArgs {
     uint32_t tiles_per_proto; // LOCAL: 32-row tiles per Omega_j
     uint64_t nbatches;
     Outputs out;
+    int stagger;              // experiment: 1 = upper half of the grid starts late, 2 = odd workgroups
+    int stagger_sleeps;
+    unsigned long long *dbg;  // diagnostic build (ABL & 4): per-wave cycle sums of the loop phases
 };
 
 namespace {
@@ -56,6 +60,15 @@ __device__ __forceinline__ uint32_t xor32(uint32_t v) { return (uint32_t)__shfl_
 __device__ __forceinline__ bool lexless(float av, uint32_t ai, float bv, uint32_t bi)
 {
     return av < bv || (av == bv && ai < bi);
+}
+
+__device__ __forceinline__ unsigned long long stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
 }
 
 template <int I, int N, class F>
@@ -227,6 +240,17 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
             stage_group<G1::STAGE_BYTES>(dst, (const char *)(a.img1 + (size_t)q * G1::STAGE_FLOATS), wave, lane);
     };
 
+    if ((a.stagger == 1 && blockIdx.x >= gridDim.x / 2) || (a.stagger == 2 && (blockIdx.x & 1)))
+        for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto lap = [&](int slot) {                        // diagnostic build only
+        if (ABL & 4) {
+            const unsigned long long t = stamp();
+            tm[slot] += t - tprev;
+            tprev = t;
+        }
+    };
+    if (ABL & 4) tprev = stamp();
     int cur = 0;
     if ((uint64_t)blockIdx.x < a.nbatches) {
         issue(0, 0);
@@ -275,10 +299,14 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
 
         // One step of the cyclic weight stream: prefetch the next stage, compute on this one, barrier.
         uint32_t q = 0;
+        lap(0);                                   // 0: sample loads issued (+ previous batch's stores)
         auto step = [&](auto &&compute) {
             if (!(ABL & 2) && !(last_batch && q + 1 == ngroups)) issue(q + 1 == ngroups ? 0u : q + 1, cur ^ 1);
+            lap(1);                               // 1: DMA issue
             compute((const float *)(smem + ((ABL & 2) ? 0 : cur) * BUF_BYTES));
+            lap(3);                               // 3: per-tile epilogue (2 = MFMA part, stamped inside)
             if (!(ABL & 2)) __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading this one
+            lap(4);                               // 4: barrier
             cur ^= 1;
             ++q;
         };
@@ -341,6 +369,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                         const float *tile = stage + tt * G2::TILE_FLOATS;
                         f32x16 acc[S];
                         tile_mma<RS, S>(tile, yf, acc, s_col, h);
+                        lap(2);
                         const uint32_t kbase = (qs * G2::G + tt) * 32 + 4 * h;
                         const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32;
 #pragma unroll
@@ -404,6 +433,159 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     }
                 }
                 if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, cls_plain, MATCHED, label[s], wp, wn);
+            }
+            if (s == S - 1) lap(5);               // 5: batch epilogue (merge, exact re-measurement)
+            if (live) {
+                if (h == 0) {
+                    if (a.out.idx) a.out.idx[sample[s]] = wp.i;
+                    if (MATCHED && a.out.jneg) a.out.jneg[sample[s]] = wn.i;
+                } else {
+                    if (a.out.dist) a.out.dist[sample[s]] = wp.d;
+                    if (MATCHED && a.out.dneg) a.out.dneg[sample[s]] = wn.d;
+                }
+            }
+        }
+    }
+    if ((ABL & 4) && a.dbg && lane == 0) {
+        lap(6);
+        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tm[i];
+    }
+}
+
+// ------------------------------------------------------------------------------ resident-prototype kernel
+// Euclidean models whose whole tile image fits in LDS (K * D <= ~36K floats; config 2 is 130 KiB):
+// "prototypes staged in LDS" once per workgroup, then every wave is independent -- no per-tile DMA,
+// no barriers, and the exact re-measurement of the candidates reads its rows from LDS as well.
+// One 512-thread workgroup per CU = 2 waves per SIMD sharing one copy of the prototypes.
+constexpr int RES_BYTES = 156 * 1024;
+
+template <int R>
+__device__ __forceinline__ float exact_sq_lds(const f32x4 (&xf)[R / 8], const float *img, uint32_t k, int h)
+{
+    using Gm = Geom<R>;
+    const uint32_t r = k & 31u;
+    const float *rowp = img + (size_t)(k >> 5) * Gm::TILE_FLOATS + r * R;
+    const int sw = Gm::swz((int)r);
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 v = *(const f32x4 *)(rowp + (((2 * j + h) ^ sw) << 2));      // v = -2 w
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = fmaf(0.5f, v[e], xf[j][e]);                          // x - w, exact scaling
+            p = fmaf(d, d, p);
+        }
+    }
+    return p + xor32(p);
+}
+
+template <int R, int S, bool MATCHED, int ABL = 0>
+__global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
+{
+    using Gm = Geom<R>;
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = a.ngroups1 * Gm::G;
+    const uint32_t Cact = a.D >> 2;
+
+    {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        const uint32_t bytes = ntiles * Gm::TILE_BYTES;
+        const char *src = (const char *)a.img1;
+        for (uint32_t p = wave; p * 1024u < bytes; p += 8) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+
+    for (uint64_t b = (uint64_t)blockIdx.x * 8 + wave; b < a.nbatches; b += (uint64_t)gridDim.x * 8) {
+        f32x4 xf[S][R / 8];
+        uint64_t sample[S];
+        uint32_t label[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sample[s] = (b * S + s) * 32 + s_col;
+            const bool live = sample[s] < a.N;
+            const float *xrow = a.X + sample[s] * a.D;
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) {
+                const uint32_t c = 2 * j + h;
+                const bool ok = live && c < Cact;
+                const f32x4 v = *(const f32x4 *)(ok ? xrow + 4 * c : a.X);
+                xf[s][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            label[s] = (MATCHED && live) ? a.y[sample[s]] : 0u;
+        }
+        Top2 top[S];
+        Best1 pos[S], neg[S];
+
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+            f32x16 acc[S];
+            tile_mma<R, S>(tile, xf, acc, s_col, h);
+            const uint32_t kbase = t * 32 + 4 * h;
+            const uint32_t *tcls = (const uint32_t *)(tile + Gm::W_FLOATS) + 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x4 cg;
+                if (MATCHED) cg = *(const u32x4 *)(tcls + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t k = kbase + 8 * g + e;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float v = acc[s][4 * g + e];
+                        if (ABL & 1) top[s].b1 = fminf(top[s].b1, v);              // timing experiment only
+                        else if (!MATCHED) top[s].offer(v, k);
+                        else if (cg[e] == label[s]) pos[s].offer(v, k);           // helpers.rs:113
+                        else neg[s].offer(v, k);                                   // helpers.rs:122
+                    }
+                }
+            }
+        }
+
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool live = sample[s] < a.N;
+            Best1 wp, wn;
+            bool rescan = false;
+            if (!MATCHED) {
+                top[s].merge_halves();
+                const Top2 &t = top[s];
+                if (t.b1 < INFINITY) {
+                    const float d1 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i1, h));
+                    wp.d = d1; wp.i = t.i1;
+                    if (t.b2 < INFINITY) {
+                        const float d2 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i2, h));
+                        if (lexless(d2, t.i2, d1, t.i1)) { wp.d = d2; wp.i = t.i2; }
+                    }
+                    rescan = t.b1 == -INFINITY || !(wp.d < INFINITY);
+                }
+            } else {
+                pos[s].merge_halves();
+                neg[s].merge_halves();
+                if (pos[s].d < INFINITY) {
+                    wp.d = sqrtf(exact_sq_lds<R>(xf[s], img, pos[s].i, h)); wp.i = pos[s].i;
+                    rescan |= pos[s].d == -INFINITY || !(wp.d < INFINITY);
+                }
+                if (neg[s].d < INFINITY) {
+                    wn.d = sqrtf(exact_sq_lds<R>(xf[s], img, neg[s].i, h)); wn.i = neg[s].i;
+                    rescan |= neg[s].d == -INFINITY || !(wn.d < INFINITY);
+                }
+            }
+            if (rescan) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
+                wp = Best1();
+                wn = Best1();
+                for (uint32_t k = 0; k < a.K; ++k) {
+                    const float d = sqrtf(exact_sq_lds<R>(xf[s], img, k, h));
+                    const uint32_t ck = MATCHED ? ((const uint32_t *)(img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::W_FLOATS))[32 + (k & 31)] : 0u;
+                    if (!MATCHED || ck == label[s]) wp.offer(d, k);
+                    else wn.offer(d, k);
+                }
             }
             if (live) {
                 if (h == 0) {
@@ -499,6 +681,18 @@ void bind(EngineModel &m)
     m.samples_per_batch = 4 * S * 32;
 }
 
+template <int R, int S, int ABL = 0>
+hipError_t launch_resident(const EngineModel &, const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;                        // one batch of S*32 samples per wave
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);          // one 512-thread workgroup per CU
+    if (matched)
+        hipLaunchKernelGGL((k_resident<R, S, true, ABL>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_resident<R, S, false, ABL>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
 int variant_env()
 {
     const char *v = getenv("VQHIP_VARIANT");     // experiments only: picks among co-compiled tilings
@@ -513,6 +707,14 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
                            m.ngroups1);
     bind<MODE_EUCLID, R1, R1, (R1 >= 256 ? 1 : 2)>(m);
+    if (R1 < 256 && (size_t)m.ngroups1 * Geom<R1>::STAGE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
+        constexpr int S = R1 >= 256 ? 1 : 2;
+        m.launch = &launch_resident<R1, S>;
+        m.samples_per_batch = S * 32;
+        m.name = "mfma_euclid_lds";
+        if (variant_env() == 21) m.launch = &launch_resident<R1, S, 1>;      // ablation: timing only
+        return true;
+    }
     if constexpr (R1 == 128) {
         const int v = variant_env();
         if (v == 1) bind<MODE_EUCLID, R1, R1, 1, 3>(m);
@@ -521,6 +723,7 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
         if (v == 11) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 1>;   // ablations: wrong results, timing only
         if (v == 12) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 2>;
         if (v == 13) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 3>;
+        if (v == 14) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 4>;   // phase stamps (diagnostic)
     }
     return true;
 }
@@ -682,7 +885,29 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.K = m->K; a.tiles_per_proto = m->tiles_per_proto;
     a.nbatches = (N + m->samples_per_batch - 1) / m->samples_per_batch;
     a.out = out;
-    return m->launch(*m, a, dy != nullptr, s);
+    a.dbg = nullptr;
+    static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
+    if (variant_env() == 14) {
+        if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
+        a.dbg = dbg_buf;
+    }
+    a.stagger = getenv("VQHIP_STAGGER") ? atoi(getenv("VQHIP_STAGGER")) : 0;
+    a.stagger_sleeps = getenv("VQHIP_SLEEPS") ? atoi(getenv("VQHIP_SLEEPS")) : 8;
+    hipError_t e = m->launch(*m, a, dy != nullptr, s);
+    if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch
+        (void)hipStreamSynchronize(s);
+        const size_t nw = 512 * 4;
+        std::vector<unsigned long long> h(nw * 8);
+        (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        for (size_t w = 0; w < nw; ++w)
+            for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
+        double tot = 0;
+        for (int i = 0; i < 7; ++i) tot += sum[i];
+        fprintf(stderr, "phase cycles per wave: loads %.0f dma %.0f mma %.0f tile_epi %.0f barrier %.0f batch_epi %.0f tail %.0f total %.0f\n",
+                sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, tot / nw);
+    }
+    return e;
 }
 
 }  // namespace vq
