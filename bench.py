@@ -12,7 +12,7 @@ the only exchange is the RCCL all-gather of winner indices + distances, issued p
 stream so it overlaps the next chunk's kernel.
 
 One JSON line on rank 0: the contract fields plus
-  roofline     dominant kernel (k_engine) against the f32 MFMA peak: algorithmic flops per launch
+  roofline     dominant kernel (k_resident_pipe for c2; k_engine otherwise) against the f32 MFMA peak: algorithmic flops per launch
                (2*K*D per sample) / mean launch time from HIP events on the launch stream
   cpu_baseline the f64 oracle (a C port of the reference's loops; the Rust reference cannot be built
                here) timed on a bounded sample on this box's host cores, rank 0, N=1 only.
@@ -28,6 +28,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
+# device function behind each kernel family name reported by vqhip_last_kernel
+KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "scalar": "k_assign_scalar"}
 
 
 def flops_per_sample(cfg):
@@ -173,7 +175,7 @@ def main():
                        "name": cfg.name, "rows_per_gpu": rows, "dim": cfg.D, "prototypes": cfg.K,
                        "gather_chunks": chunks, "kernel": ctx.last_kernel,
                        "exchange": "rccl all_gather(idx u32, dist f32)" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "k_engine", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": KERNEL_FN.get(ctx.last_kernel, "k_engine"), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "launch_ms": launch_ms, "flops_per_sample": fl, "samples_per_launch": m_rows,
                          "hbm_GBps_algorithmic": m_rows * bytes_per_sample(cfg) / (launch_ms * 1e-3) / 1e9,
@@ -181,10 +183,10 @@ def main():
         }
         cpu_rows = args.cpu_rows
         if cpu_rows < 0:
-            # ~10-20 s of single-core work: K*D multiply-adds per sample (Euclidean), K*(M*D*D + D*D) when
+            # ~15 s of single-core work: K*D multiply-adds per sample (Euclidean), K*(M*D*D + D*D) when
             # Lambda is rebuilt for every (sample, prototype) pair like src/helpers.rs:38
             per_sample = cfg.K * cfg.D if cfg.omega == "none" else cfg.K * (cfg.M * cfg.D * cfg.D + cfg.D * cfg.D)
-            cpu_rows = 0 if world > 1 else max(16, int(1.2e10 / per_sample))
+            cpu_rows = 0 if world > 1 else max(16, int(4.5e10 / per_sample))
         if cpu_rows:
             import oracle                                   # the checker, used here only as the timed CPU baseline
 

@@ -28,19 +28,18 @@ template <int R>
 struct Geom {
     static_assert(R >= 8 && R <= 256 && (R & (R - 1)) == 0, "reduction length: power of two in [8, 256]");
     static constexpr int C = R / 4;                           // 16-byte chunks per row
-    static constexpr int W_FLOATS = TILE_ROWS * R;
+    // Rows are padded by one chunk: consecutive rows start 4 banks apart (mod 64), so a ds_read_b128
+    // by 16 lanes holding 16 consecutive rows (same chunk) touches 16 different 16-byte bank slots,
+    // and every chunk of a row sits at a compile-time offset from one per-lane row address.
+    static constexpr int ROW_FLOATS = R + 4;
+    static constexpr int W_FLOATS = TILE_ROWS * ROW_FLOATS;
     static constexpr int TILE_FLOATS = W_FLOATS + TAIL_FLOATS;
     static constexpr int TILE_BYTES = TILE_FLOATS * 4;
     static constexpr int G = R >= 128 ? 1 : 128 / R;          // tiles per LDS stage (~16 KiB of weights)
     static constexpr int STAGE_FLOATS = G * TILE_FLOATS;
     static constexpr int STAGE_BYTES = STAGE_FLOATS * 4;
-    // XOR swizzle of the chunk index so that a ds_read_b128 by 16 lanes holding 16 different rows
-    // (same chunk) touches 16 different 16-byte slots of the 256-byte bank row.
-    static constexpr int SWZ_SHIFT = C >= 16 ? 0 : ilog2(16 / C);
-    static constexpr int SWZ_MASK = (C >= 16 ? 16 : C) - 1;
-    __host__ __device__ static constexpr int swz(int row) { return (row >> SWZ_SHIFT) & SWZ_MASK; }
     // float offset of (row, chunk c) inside a tile image
-    __host__ __device__ static constexpr int chunk_off(int row, int c) { return (row * C + (c ^ swz(row))) * 4; }
+    __host__ __device__ static constexpr int chunk_off(int row, int c) { return row * ROW_FLOATS + c * 4; }
 };
 
 }  // namespace vq

@@ -14,6 +14,7 @@
 // One workgroup = 4 waves; each wave keeps S tiles of 32 samples in registers and all waves walk
 // the same stream of weight-tile groups through a double-buffered LDS stage filled by LDS-DMA
 // (global_load_lds_dwordx4), one barrier per group.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,6 +47,7 @@ struct EngineArgs {
     uint32_t tiles_per_proto; // LOCAL: 32-row tiles per Omega_j
     uint64_t nbatches;
     Outputs out;
+    float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
     int stagger;              // experiment: 1 = upper half of the grid starts late, 2 = odd workgroups
     int stagger_sleeps;
     unsigned long long *dbg;  // diagnostic build (ABL & 4): per-wave cycle sums of the loop phases
@@ -161,11 +163,10 @@ __device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S]
             acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
         }
     }
-    const int sw = Gm::swz(row);
-    const float *rowp = tile + row * R;
+    const float *rowp = tile + Gm::chunk_off(row, h);
 #pragma unroll
     for (int j = 0; j < R / 8; ++j) {
-        const f32x4 a = *(const f32x4 *)(rowp + (((2 * j + h) ^ sw) << 2));
+        const f32x4 a = *(const f32x4 *)(rowp + 8 * j);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -464,12 +465,11 @@ __device__ __forceinline__ float exact_sq_lds(const f32x4 (&xf)[R / 8], const fl
 {
     using Gm = Geom<R>;
     const uint32_t r = k & 31u;
-    const float *rowp = img + (size_t)(k >> 5) * Gm::TILE_FLOATS + r * R;
-    const int sw = Gm::swz((int)r);
+    const float *rowp = img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::chunk_off((int)r, h);
     float p = 0.0f;
 #pragma unroll
     for (int j = 0; j < R / 8; ++j) {
-        const f32x4 v = *(const f32x4 *)(rowp + (((2 * j + h) ^ sw) << 2));      // v = -2 w
+        const f32x4 v = *(const f32x4 *)(rowp + 8 * j);                          // v = -2 w
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float d = fmaf(0.5f, v[e], xf[j][e]);                          // x - w, exact scaling
@@ -600,6 +600,371 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------ pipelined resident kernel
+// Same contract as k_resident.  What it is built around (measured on MI355X):
+//   * v_mfma_f32_32x32x2_f32 runs at the f32 vector rate and does not co-execute with VALU work of
+//     the same SIMD: kernel time ~ 64 cycles per MFMA + 4 cycles per VALU instruction.  So the
+//     screening of the scores is cut to 4 VALU per score (packed keys, below) instead of 8.
+//   * every wave of the chip loading its samples and then computing, in lockstep, leaves HBM idle
+//     during the search and the matrix pipe idle during the loads: the next batch's rows are
+//     fetched into a second register set while the current batch is searched.
+//   * the two waves of a SIMD do not share the matrix pipe evenly, so batches are claimed from a
+//     queue instead of being dealt out.
+//
+// Packed keys.  The accumulator of a (weight tile, sample tile) starts at ||w_k||^2 + c with
+// c = ||x||^2 (1 + 2^-8) + tiny, so a finished score is ||x - w_k||^2 + (c - ||x||^2) > 0 and its f32
+// bit pattern orders like an unsigned integer.  The low 4 mantissa bits are replaced by the row's
+// position o among the lane's 16 rows of the tile; v_min_u32 / v_med3_u32 keep the best two keys
+// of a lane, and which TILE they came from is settled once per tile by comparing the pair before
+// and after.  Equal scores keep the lower index at every level (o inside a tile, the older tile
+// across tiles, the lower k across the lane pair), NaN / -INF / pad-row (+INF) patterns sort above
+// every finite score, and the two candidates are re-measured exactly as before.  Samples whose
+// ||x||^2 is not safely finite go to the exact in-order scan.
+struct Keys2 {                       // unlabelled search: best two keys and their tiles
+    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, t1 = 0u, t2 = 0u;
+};
+struct KeysM {                       // labelled search: best key with cls == y, best with cls != y
+    uint32_t p = 0xFFFFFFFFu, n = 0xFFFFFFFFu, tp = 0u, tn = 0u;
+};
+constexpr uint32_t KEY_VALID_BELOW = 0x7F800000u;   // keys of finite non-negative scores
+
+__device__ __forceinline__ uint32_t pack_key(float score, uint32_t o)
+{
+    uint32_t key;                                   // (bits & ~15) | o in one instruction
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(score), "s"(0xFFFFFFF0u), "n"(o));
+    return key;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ uint32_t key_row(uint32_t key, uint32_t tile, int h)   // prototype index of a key
+{
+    const uint32_t o = key & 15u;
+    return tile * 32u + ((o >> 2) << 3) + (o & 3u) + 4u * (uint32_t)h;
+}
+
+// On entry:  acc = accumulator-init column of `tile` (+ c), a0 = this lane's chunk 0 of `tile`,
+//            prev = finished scores of tile number `tprev_id` (class ids in tprev's tail).
+// On exit:   acc = scores of (tile, xf), prev = init column of `next` (+ c), a0 = chunk 0 of `next`.
+template <int R, bool MATCHED>
+__device__ __forceinline__ void half_step(const float *tile, const float *next, const float *tprev, uint32_t tprev_id,
+                                          uint32_t label, float c, const f32x4 (&xf)[R / 8], f32x16 &acc, f32x16 &prev,
+                                          f32x4 &a0, int row, int h, Keys2 &ku, KeysM &km)
+{
+    using Gm = Geom<R>;
+    constexpr int NM = R / 2;                          // MFMAs of this half-step
+    constexpr int SPAN = R >= 32 ? NM / 2 : NM;        // the 16 keys are spread over the first SPAN MFMAs
+    constexpr int CI = NM / 2;                         // MFMA after which the next init column is fetched
+    const float *rowp = tile + Gm::chunk_off(row, h);
+    f32x4 acur = a0, anext = a0;
+    f32x16 cnext;
+    const Keys2 ou = ku;
+    const KeysM om = km;
+    // class ids of the screened tile's rows, one group of 4 rows ahead of the keys that use them
+    const uint32_t *tcls = (const uint32_t *)(tprev + Gm::W_FLOATS) + 32 + 4 * h;
+    u32x4 cgc = {0u, 0u, 0u, 0u}, cgn = {0u, 0u, 0u, 0u};
+    if (MATCHED) cgn = *(const u32x4 *)tcls;
+    static_for<0, NM>([&](auto ii) {
+        constexpr int i = decltype(ii)::value, j = i / 4, e = i % 4;
+        if constexpr (e == 0) {
+            acur = anext;
+            if constexpr (j + 1 < R / 8)
+                anext = *(const f32x4 *)(rowp + 8 * (j + 1));
+            else
+                a0 = *(const f32x4 *)(next + Gm::chunk_off(row, h));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[e], xf[j][e], acc, 0, 0, 0);
+        constexpr int o0 = i * 16 / SPAN < 16 ? i * 16 / SPAN : 16;
+        constexpr int o1 = (i + 1) * 16 / SPAN < 16 ? (i + 1) * 16 / SPAN : 16;
+        static_for<o0, o1>([&](auto oo) {
+            constexpr int o = decltype(oo)::value;
+            const uint32_t key = pack_key(prev[o], o);
+            if constexpr (!MATCHED) {
+                ku.b2 = umed3(ku.b1, ku.b2, key);             // second smallest of {b1 <= b2, key}
+                ku.b1 = ku.b1 < key ? ku.b1 : key;
+            } else {
+                if constexpr ((o & 3) == 0) {
+                    cgc = cgn;
+                    if constexpr (o + 4 < 16) cgn = *(const u32x4 *)(tcls + 8 * ((o >> 2) + 1));
+                }
+                const bool match = cgc[o & 3] == label;           // helpers.rs:113 / :122
+                const uint32_t kp = match ? key : 0xFFFFFFFFu, kn = match ? 0xFFFFFFFFu : key;
+                km.p = km.p < kp ? km.p : kp;
+                km.n = km.n < kn ? km.n : kn;
+            }
+        });
+        if constexpr (o0 < 16 && o1 == 16) {              // all 16 keys of the tile are in: settle the tiles
+            if constexpr (!MATCHED) {
+                const bool c1 = ku.b1 != ou.b1, c2 = ku.b2 != ou.b2;
+                const uint32_t demoted = ku.b2 == ou.b1 ? ou.t1 : tprev_id;
+                ku.t2 = c1 ? demoted : (c2 ? tprev_id : ou.t2);
+                ku.t1 = c1 ? tprev_id : ou.t1;
+            } else {
+                km.tp = km.p != om.p ? tprev_id : om.tp;
+                km.tn = km.n != om.n ? tprev_id : om.tn;
+            }
+        }
+        if constexpr (i == CI) {
+            const float *tail = next + Gm::W_FLOATS;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+                cnext[4 * g + 0] = ci[0] + c; cnext[4 * g + 1] = ci[1] + c;
+                cnext[4 * g + 2] = ci[2] + c; cnext[4 * g + 3] = ci[3] + c;
+            }
+        }
+    });
+    prev = cnext;
+}
+
+// Screening of the last tile of a batch (no MFMAs left to run beside it).
+template <int R, bool MATCHED>
+__device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tprev, uint32_t tprev_id, uint32_t label, int h,
+                                            Keys2 &ku, KeysM &km)
+{
+    const uint32_t *tcls = (const uint32_t *)(tprev + Geom<R>::W_FLOATS) + 32 + 4 * h;
+    const Keys2 ou = ku;
+    const KeysM om = km;
+    static_for<0, 16>([&](auto oo) {
+        constexpr int o = decltype(oo)::value;
+        const uint32_t key = pack_key(prev[o], o);
+        if constexpr (!MATCHED) {
+            ku.b2 = umed3(ku.b1, ku.b2, key);
+            ku.b1 = ku.b1 < key ? ku.b1 : key;
+        } else {
+            const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;
+            const uint32_t kp = match ? key : 0xFFFFFFFFu, kn = match ? 0xFFFFFFFFu : key;
+            km.p = km.p < kp ? km.p : kp;
+            km.n = km.n < kn ? km.n : kn;
+        }
+    });
+    if (!MATCHED) {
+        const bool c1 = ku.b1 != ou.b1, c2 = ku.b2 != ou.b2;
+        const uint32_t demoted = ku.b2 == ou.b1 ? ou.t1 : tprev_id;
+        ku.t2 = c1 ? demoted : (c2 ? tprev_id : ou.t2);
+        ku.t1 = c1 ? tprev_id : ou.t1;
+    } else {
+        km.tp = km.p != om.p ? tprev_id : om.tp;
+        km.tn = km.n != om.n ? tprev_id : om.tn;
+    }
+}
+
+__device__ __forceinline__ bool keyless(uint32_t ak, uint32_t ai, uint32_t bk, uint32_t bi)
+{
+    return ak < bk || (ak == bk && ai < bi);
+}
+
+// Final step of a batch: the lane pair agrees on the candidates, re-measures them in the direct
+// (x - w)^2 form from the LDS image, roots, compares like helpers.rs:70.
+template <int R, bool MATCHED>
+__device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h,
+                                            bool unsafe, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
+{
+    using Gm = Geom<R>;
+    if (!MATCHED) {
+        // this lane's two candidates and the partner lane's, best two of the four by (key, index)
+        const uint32_t k1 = key_row(ku.b1, ku.t1, h), k2 = key_row(ku.b2, ku.t2, h);
+        const uint32_t pb1 = xor32(ku.b1), pb2 = xor32(ku.b2), pk1 = xor32(k1), pk2 = xor32(k2);
+        uint32_t f, fi, sd, si;
+        if (keyless(pb1, pk1, ku.b1, k1)) {
+            f = pb1; fi = pk1;
+            if (keyless(ku.b1, k1, pb2, pk2)) { sd = ku.b1; si = k1; } else { sd = pb2; si = pk2; }
+        } else {
+            f = ku.b1; fi = k1;
+            if (keyless(pb1, pk1, ku.b2, k2)) { sd = pb1; si = pk1; } else { sd = ku.b2; si = k2; }
+        }
+        if (f < KEY_VALID_BELOW && !unsafe) {
+            const float d1 = sqrtf(exact_sq_lds<R>(xf, img, fi, h));
+            wp.d = d1; wp.i = fi;
+            if (sd < KEY_VALID_BELOW) {
+                const float d2 = sqrtf(exact_sq_lds<R>(xf, img, si, h));
+                if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+            }
+            unsafe = !(wp.d < INFINITY);
+        } else {
+            unsafe = true;
+        }
+    } else {
+        uint32_t kp = key_row(km.p, km.tp, h), kn = key_row(km.n, km.tn, h), p = km.p, n = km.n;
+        const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
+        if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
+        if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
+        if (p < KEY_VALID_BELOW) {
+            wp.d = sqrtf(exact_sq_lds<R>(xf, img, kp, h)); wp.i = kp;
+            unsafe |= !(wp.d < INFINITY);
+        }
+        if (n < KEY_VALID_BELOW) {
+            wn.d = sqrtf(exact_sq_lds<R>(xf, img, kn, h)); wn.i = kn;
+            unsafe |= !(wn.d < INFINITY);
+        }
+    }
+    if (unsafe) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
+        wp = Best1();
+        wn = Best1();
+        for (uint32_t k = 0; k < K; ++k) {
+            const float d = sqrtf(exact_sq_lds<R>(xf, img, k, h));
+            const uint32_t ck = MATCHED ? ((const uint32_t *)(img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::W_FLOATS))[32 + (k & 31)] : 0u;
+            if (!MATCHED || ck == label) wp.offer(d, k);
+            else wn.offer(d, k);
+        }
+    }
+}
+
+// One wave = one tile of 32 samples per batch.  D == R (host checks); the image has an even number of
+// tiles (the accumulators ping-pong).  a.ss_limit: ||x||^2 below which no score can overflow.
+template <int R, bool MATCHED, bool DIAG = false, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
+{
+    using Gm = Geom<R>;
+    unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = 0;
+    auto lap = [&](int slot) {                        // diagnostic build only
+        if (DIAG) {
+            const unsigned long long t = stamp();
+            tm[slot] += t - tprev_;
+            tprev_ = t;
+        }
+    };
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    __shared__ uint32_t queue_head;                   // next unclaimed batch of this workgroup
+    const unsigned long long r_entry = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = a.ngroups1 * Gm::G;       // even (host pads)
+
+    {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        const uint32_t bytes = ntiles * Gm::TILE_BYTES;
+        const char *src = (const char *)a.img1;
+        for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        if (threadIdx.x == 0) queue_head = 0u;
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+    unsigned long long t_begin = 0, r_begin = 0;
+    if (DIAG) {
+        tprev_ = t_begin = stamp();
+        r_begin = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // Workgroup w owns batches w, w + gridDim, w + 2 gridDim, ...; its waves claim them from a queue
+    // in LDS (the older wave of a SIMD wins the arbitration for the matrix pipe, so a fixed split
+    // would leave the younger one alone with a quarter of its batches after its partner has exited).
+    auto claim = [&]() -> uint64_t {
+        uint32_t q = 0u;
+        if (lane == 0) q = __hip_atomic_fetch_add(&queue_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        return (uint64_t)blockIdx.x + (uint64_t)gridDim.x * q;
+    };
+    // Rows come in through a buffer descriptor rebased per batch (wave-uniform, so the 4 GiB offset
+    // range is per batch, not per matrix): rows past N read as zeros by the hardware range check, one
+    // per-lane offset serves every chunk (immediate offsets), and nothing needs a 64-bit address.
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    f32x4 xn[R / 8];                                   // rows of the next batch, in flight
+    uint32_t ln = 0u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {      // bytes from row bb*32 to the end, clamped
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    auto fetch = [&](uint64_t bb) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j)
+            xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    uint64_t b = claim();
+    fetch(b);
+
+    while (b < a.nbatches) {
+        const uint64_t bnext = claim();
+        f32x4 xf[R / 8];
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j) {
+            xf[j] = xn[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss = fmaf(xf[j][e], xf[j][e], ss);
+        }
+        const uint32_t label = ln;
+        ss += xor32(ss);                               // ||x||^2, the same value in both lanes of the pair
+        const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge rows: exact scan at the end
+        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+        lap(0);                                        // 0: delivery of this batch's rows
+        fetch(bnext);
+        lap(1);                                        // 1: issue of the next batch's loads
+
+        Keys2 ku;
+        KeysM km;
+        f32x16 acc0, acc1;
+        f32x4 a0 = *(const f32x4 *)(img + Gm::chunk_off(s_col, h));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(img + Gm::W_FLOATS + 8 * g + 4 * h);
+            acc0[4 * g + 0] = ci[0] + c; acc0[4 * g + 1] = ci[1] + c; acc0[4 * g + 2] = ci[2] + c; acc0[4 * g + 3] = ci[3] + c;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = INFINITY;             // "tile -1": its keys never win
+        const float *tprev = img;
+        uint32_t tid = 0;
+        for (uint32_t t = 0; t < ntiles; t += 2) {
+            const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+            const float *tile1 = tile + Gm::TILE_FLOATS;
+            const float *next = t + 2 < ntiles ? tile1 + Gm::TILE_FLOATS : img;
+            // tile t computes into acc0 while tile t-1 (in acc1) is screened; acc1 leaves as the init column of t+1
+            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, c, xf, acc0, acc1, a0, s_col, h, ku, km);
+            // tile t+1 computes into acc1 while tile t (in acc0) is screened; acc0 leaves as the init column of t+2
+            half_step<R, MATCHED>(tile1, next, tile, t, label, c, xf, acc1, acc0, a0, s_col, h, ku, km);
+            tprev = tile1;
+            tid = t + 1;
+        }
+        last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+        lap(2);                                        // 2: tile loop
+
+        Best1 wp, wn;
+        finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, ku, km, wp, wn);
+        {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
+            const int rec = (int)records(b, 4u);
+            const uint32_t so = (uint32_t)s_col * 4u;
+            auto put = [&](void *base, uint32_t bits) {
+                __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+            };
+            if (h == 0) {
+                if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+            } else {
+                if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+            }
+        }
+        lap(3);                                        // 3: batch epilogue
+        b = bnext;
+    }
+    if (DIAG && a.dbg && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 4; ++i) d[i] = tm[i];
+        d[0] = r_begin - r_entry;                          // image load, 100 MHz ticks
+        d[4] = stamp() - t_begin;                          // shader cycles of the batch loop
+        d[5] = __builtin_amdgcn_s_memrealtime() - r_begin; // the same span in 100 MHz ticks
+        d[6] = r_begin;
+        d[7] = r_begin + d[5];
+    }
+}
+
 // ------------------------------------------------------------------------------ host side
 struct EngineModel {
     int mode = MODE_EUCLID;
@@ -611,6 +976,7 @@ struct EngineModel {
     const char *name = "mfma";
     hipError_t (*launch)(const EngineModel &, const EngineArgs &, bool matched, hipStream_t) = nullptr;
     int samples_per_batch = 0;
+    float ss_limit = 0.0f;
 };
 
 namespace {
@@ -693,6 +1059,22 @@ hipError_t launch_resident(const EngineModel &, const EngineArgs &a, bool matche
     return hipGetLastError();
 }
 
+template <int R, bool DIAG = false>
+hipError_t launch_resident_pipe(const EngineModel &, const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    if (DIAG && getenv("VQHIP_NW4"))
+        hipLaunchKernelGGL((k_resident_pipe<R, false, true, 4>), dim3(grid), dim3(256), 0, st, a);
+    else if (DIAG)
+        hipLaunchKernelGGL((k_resident_pipe<R, false, true>), dim3(grid), dim3(512), 0, st, a);
+    else if (matched)
+        hipLaunchKernelGGL((k_resident_pipe<R, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_resident_pipe<R, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
 int variant_env()
 {
     const char *v = getenv("VQHIP_VARIANT");     // experiments only: picks among co-compiled tilings
@@ -704,15 +1086,20 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
                  const std::vector<uint32_t> &cls)
 {
     if (m.R1 != (uint32_t)R1) return false;
+    // an even number of tiles: the pipelined kernel ping-pongs two accumulators (pad rows score +INF)
     img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
-                           m.ngroups1);
+                           m.ngroups1, ((size_t)m.K + 63) / 64 * 64);
     bind<MODE_EUCLID, R1, R1, (R1 >= 256 ? 1 : 2)>(m);
     if (R1 < 256 && (size_t)m.ngroups1 * Geom<R1>::STAGE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
         constexpr int S = R1 >= 256 ? 1 : 2;
         m.launch = &launch_resident<R1, S>;
         m.samples_per_batch = S * 32;
         m.name = "mfma_euclid_lds";
-        if (variant_env() == 21) m.launch = &launch_resident<R1, S, 1>;      // ablation: timing only
+        if (m.D == (uint32_t)R1 && !getenv("VQHIP_NO_PIPE")) {       // unpadded rows: the pipelined kernel
+            m.samples_per_batch = 32;
+            m.launch = variant_env() == 31 ? &launch_resident_pipe<R1, true> : &launch_resident_pipe<R1>;
+            m.name = "mfma_euclid_lds_pipe";
+        }
         return true;
     }
     if constexpr (R1 == 128) {
@@ -801,16 +1188,20 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
         }
         const std::vector<float> &Q = omega_kind == OMEGA_NONE ? W : P;
         std::vector<float> norms(K);
+        double wmax2 = 0.0;
         for (uint32_t k = 0; k < K; ++k) {
             double t = 0.0;
             for (uint32_t d = 0; d < L; ++d) t += (double)Q[(size_t)k * L + d] * (double)Q[(size_t)k * L + d];
             norms[k] = (float)t;
+            wmax2 = t > wmax2 ? t : wmax2;
             // The screening form needs ||p||^2 and 2 p.x inside f32 range; the scalar kernels do not.
             if (!(t < 1e37)) {
                 why = "a prototype's squared norm is not finite in f32";
                 return nullptr;
             }
         }
+        // ||x||^2 below this: |2 x.w| <= 2 sqrt(ss wmax2) <= 1e18 and ||w||^2 + c stay far inside f32 range
+        m.ss_limit = (float)std::min(1e36, 1e36 / (4.0 * std::max(wmax2, 1e-36)));
         if (omega_kind == OMEGA_NONE) {
             m.mode = MODE_EUCLID;
             m.name = "mfma_euclid";
@@ -885,9 +1276,10 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.K = m->K; a.tiles_per_proto = m->tiles_per_proto;
     a.nbatches = (N + m->samples_per_batch - 1) / m->samples_per_batch;
     a.out = out;
+    a.ss_limit = m->ss_limit;
     a.dbg = nullptr;
     static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
-    if (variant_env() == 14) {
+    if (variant_env() == 14 || variant_env() == 31) {
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
@@ -904,6 +1296,22 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
             for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
         double tot = 0;
         for (int i = 0; i < 7; ++i) tot += sum[i];
+        if (variant_env() == 31) {
+            double s4[6] = {0};
+            for (size_t w = 0; w < (size_t)256 * (getenv("VQHIP_NW4") ? 4 : 8); ++w)
+                for (int i = 0; i < 6; ++i) s4[i] += (double)h[w * 8 + i];
+            unsigned long long b0 = ~0ull, b1 = 0, e0 = ~0ull, e1 = 0;
+            for (size_t w = 0; w < (size_t)256 * (getenv("VQHIP_NW4") ? 4 : 8); ++w) {
+                b0 = std::min(b0, h[w * 8 + 6]); b1 = std::max(b1, h[w * 8 + 6]);
+                e0 = std::min(e0, h[w * 8 + 7]); e1 = std::max(e1, h[w * 8 + 7]);
+            }
+            fprintf(stderr, "loop start spread %.1f us, first start -> first end %.1f us, -> last end %.1f us\n", (b1 - b0) / 100.0,
+                    (e0 - b0) / 100.0, (e1 - b0) / 100.0);
+            fprintf(stderr, "in-kernel clock %.3f GHz (span %.0f cycles = %.1f us)\n", s4[4] / s4[5] * 0.1, s4[4] / (getenv("VQHIP_NW4") ? 1024 : 2048), s4[5] / (getenv("VQHIP_NW4") ? 1024 : 2048) / 100.0);
+            const double nwv = getenv("VQHIP_NW4") ? 1024 : 2048;
+            fprintf(stderr, "pipe phase cycles per wave: image_load(10ns ticks) %.0f prefetch_issue %.0f tiles %.0f epilogue %.0f\n", s4[0] / nwv,
+                    s4[1] / nwv, s4[2] / nwv, s4[3] / nwv);
+        } else
         fprintf(stderr, "phase cycles per wave: loads %.0f dma %.0f mma %.0f tile_epi %.0f barrier %.0f batch_epi %.0f tail %.0f total %.0f\n",
                 sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, tot / nw);
     }
