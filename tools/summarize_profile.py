@@ -24,8 +24,10 @@ def counter(kind, name_part):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if name_part in r["Kernel_Name"]]
     return vals
 
-fetch = counter("pmc_fetch", "vq::k_")
-write = counter("pmc_write", "vq::k_")
+import re
+dom_fn = re.search(r"vq::(k_\w+)", dom["Name"]).group(1)      # counters of the dominant kernel only
+fetch = counter("pmc_fetch", "vq::" + dom_fn + "<")
+write = counter("pmc_write", "vq::" + dom_fn + "<")
 synth_w = counter("pmc_write", "k_synth_fill")
 out = {
     "workload": workload,
