@@ -95,6 +95,15 @@ int vqhip_set_kernel_policy(vqhip_ctx *ctx, int policy /* vqhip_kernel_policy */
  * Host-pointer form: samples go up in pinned, double-buffered chunks. */
 int vqhip_assign(vqhip_ctx *ctx, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out);
 
+/* The same for the reference's own container: `data: &Vec<Array1<f64>>` (src/vq/vq.rs:142), N separately
+ * allocated rows of D doubles.  rows[i] points at row i; every row must hold D values (the reference
+ * checks only data[0], src/vq/vq.rs:69, and panics inside euclidean_distance on a later ragged row,
+ * src/helpers.rs:14 -- the caller asserts the lengths).  The rows are gathered and narrowed to f32
+ * straight into the pinned upload buffers by the host cores, overlapped with the previous chunk's
+ * upload and kernel. */
+int vqhip_assign_rows_f64(vqhip_ctx *ctx, const double *const *rows, uint64_t N, uint32_t D, uint32_t *idx_out,
+                          float *dist_out);
+
 /* Same with device-resident X / outputs, enqueued on `stream` (a hipStream_t; NULL = the
  * default stream) without host synchronisation. */
 int vqhip_assign_device(vqhip_ctx *ctx, const float *dX, uint64_t N, uint32_t *didx_out,
@@ -109,6 +118,18 @@ int vqhip_assign_matched(vqhip_ctx *ctx, const float *X, const uint32_t *y, uint
 int vqhip_assign_matched_device(vqhip_ctx *ctx, const float *dX, const uint32_t *dy, uint64_t N,
                                 uint32_t *djpos, float *ddpos, uint32_t *djneg, float *ddneg,
                                 void *stream);
+
+/* ---- the Euclidean path in the reference's own number type ------------
+ * euclidean_distance + find_closest_prototype{,_matched} in f64 (src/helpers.rs:11-24, 55-77, 91-132):
+ * the same operations in the same order as the reference (index-order sum, separate multiply and
+ * add, IEEE sqrt), so index AND distance are bit-identical to it.  This is the on-device check of
+ * the argmin / tie / NaN logic without f32 rounding in the way; it is not the fast path.
+ * vqhip_set_prototypes_f64 also installs the narrowed f32 model (resetting labels and Omega like
+ * vqhip_set_prototypes), so both paths describe the same prototypes; set labels afterwards. */
+int vqhip_set_prototypes_f64(vqhip_ctx *ctx, const double *W, uint32_t K, uint32_t D);
+int vqhip_assign_f64(vqhip_ctx *ctx, const double *X, uint64_t N, uint32_t *idx_out, double *dist_out);
+int vqhip_assign_matched_f64(vqhip_ctx *ctx, const double *X, const uint32_t *y, uint64_t N, uint32_t *jpos,
+                             double *dpos, uint32_t *jneg, double *dneg);
 
 /* ---- introspection / measurement support ------------------------------------------------- */
 

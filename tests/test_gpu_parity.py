@@ -255,3 +255,124 @@ def test_host_path_multi_chunk(ctx):
         o = oracle.assign(X[lo:lo + 1000], m.W)
         rep = parity.compare(idx[lo:lo + 1000], dist[lo:lo + 1000], *o)
         assert rep.ok, str(rep)
+
+
+# ------------------------------------------------------------------ ties at scale (packed-key screening)
+
+@pytest.mark.parametrize("sign", ["positive_scores", "negative_scores"])
+def test_duplicate_prototypes_keep_the_lowest_index(ctx, sign):
+    """Every prototype appears 4 times (k, k+64, k+128, k+192): all four distances are bit-identical and
+    helpers.rs:70 keeps the first.  Exercises the tie rules of the pipelined kernel at every level
+    (inside a lane's tile, across tiles, across the lane pair); samples far from / close to the
+    origin make the raw screening scores ||w||^2 - 2 x.w positive / negative."""
+    rng = np.random.default_rng(7)
+    D, K, N = 128, 256, 4096
+    base = rng.uniform(-1, 1, size=(64, D)).astype(np.float32)
+    W = np.concatenate([base, base, base, base], axis=0)
+    X = (base[rng.integers(0, 64, size=N)] + 0.05 * rng.uniform(-1, 1, size=(N, D))).astype(np.float32)
+    if sign == "positive_scores":
+        X *= np.float32(0.01)
+    o = oracle.assign(X, W, threads=8)
+    assert (o[0] < 64).all()
+    for policy in POLICIES:
+        ctx.set_kernel_policy(policy)
+        ctx.set_prototypes(W)
+        idx, dist = ctx.assign(X)
+        rep = parity.compare(idx, dist, *o)
+        assert rep.ok and rep.mismatches == 0, f"{ctx.last_kernel}: {rep}"
+
+
+@pytest.mark.parametrize("K", [1, 2, 31, 33, 64, 65, 255, 256])
+def test_pipelined_kernel_prototype_counts(ctx, K):
+    """K around the tile (32) and tile-pair (64) boundaries: pad rows must never win."""
+    rng = np.random.default_rng(K)
+    D, N = 128, 2000
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    idx, dist = ctx.assign(X)
+    assert ctx.last_kernel == "mfma_euclid_lds_pipe"
+    rep = parity.compare(idx, dist, *oracle.assign(X, W, threads=8))
+    assert rep.ok, str(rep)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    ctx.set_labels(cls)
+    jp, dp, jn, dn = ctx.assign_matched(X, y)
+    for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+        rep = parity.compare(j, d, *oracle.assign(X, W, proto_cls=cls, labels=y, matching=matching, threads=8))
+        assert rep.ok, f"K={K} matching={matching}: {rep}"
+
+
+def test_huge_and_tiny_magnitudes(ctx):
+    """Rows whose ||x||^2 overflows f32 (exact scan) next to ordinary and denormal-scale rows."""
+    rng = np.random.default_rng(3)
+    D, K, N = 128, 256, 512
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    X[::7] *= np.float32(1e30)
+    X[3::7] *= np.float32(1e-30)
+    X[5::7] *= np.float32(3e18)
+    o = oracle.assign(X, W, threads=8)
+    for policy in POLICIES:
+        ctx.set_kernel_policy(policy)
+        ctx.set_prototypes(W)
+        idx, dist = ctx.assign(X)
+        fin = np.isfinite(dist)           # f32 overflows where f64 does not: compare the finite rows only
+        rep = parity.compare(idx[fin], dist[fin], o[0][fin], o[1][fin], o[2][fin])
+        assert rep.ok, f"{ctx.last_kernel}: {rep}"
+        assert fin[3::7].all() and fin[1::7].all()
+
+
+# ------------------------------------------------------------------ f64 entry points (SURVEY 8, rows f2 / f4)
+
+def test_f64_euclidean_path_is_bit_exact(ctx):
+    """Same operations in the same order as src/helpers.rs:11-24, 55-77: indices AND distances equal
+    the oracle's bit for bit, near-ties included."""
+    rng = np.random.default_rng(11)
+    for (N, D, K) in ((3000, 128, 256), (500, 7, 5), (64, 1, 2)):
+        W = rng.uniform(-1, 1, size=(K, D))
+        X = rng.uniform(-1, 1, size=(N, D))
+        X[N // 2] = W[K - 1]                       # an exact hit: distance 0
+        W[0] = W[K - 1]                            # and a tie for it: index 0 must win
+        ctx.set_prototypes_f64(W)
+        idx, dist = ctx.assign_f64(X)
+        assert ctx.last_kernel == "scalar_f64"
+        o_idx, o_best, _ = oracle.assign(X, W, threads=8)
+        assert (idx == o_idx).all()
+        assert (dist.view(np.uint64) == np.asarray(o_best).view(np.uint64)).all()
+        assert idx[N // 2] == 0 and dist[N // 2] == 0.0
+        cls = (np.arange(K) % 2).astype(np.uint32)
+        y = rng.integers(0, 2, size=N).astype(np.uint32)
+        ctx.set_labels(cls)
+        jp, dp, jn, dn = ctx.assign_f64(X, y)
+        for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+            oi, ob, _ = oracle.assign(X, W, proto_cls=cls, labels=y, matching=matching, threads=8)
+            assert (j == oi).all()
+            assert (d.view(np.uint64) == np.asarray(ob).view(np.uint64)).all()
+
+
+def test_f64_path_golden_vectors(ctx, kat):
+    for case in kat:
+        if case["kind"] != "euclid" or "expect_idx" not in case:
+            continue
+        ctx.set_prototypes_f64(np.array(case["prototypes"], dtype=np.float64))
+        idx, dist = ctx.assign_f64(np.array(case["data"], dtype=np.float64))
+        assert idx.tolist() == case["expect_idx"], case["name"]
+        assert_dist_close(dist, case["expect_dist"], 1e-15, case["name"])
+
+
+def test_assign_rows_f64_equals_contiguous_f32(ctx):
+    """The reference's container (separately allocated f64 rows) through the packing entry point."""
+    m = _model(("t", "GLVQ", 9000, 128, 256, 0, "none"))
+    X32 = synth.samples_host(m, 0, 9000)
+    rows = [np.array(r, dtype=np.float64) for r in X32]          # one allocation per row
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    synth.load_model(ctx, m, with_labels=False)
+    i0, d0 = ctx.assign(X32)
+    i1, d1 = ctx.assign_rows(rows)
+    assert (i0 == i1).all() and (d0 == d1).all()
+    i2, _ = ctx.assign_rows([], want_dist=False)
+    assert i2.shape == (0,)
+    with pytest.raises(ValueError):
+        ctx.assign_rows([np.zeros(128), np.zeros(127)])          # ragged row (src/helpers.rs:14)

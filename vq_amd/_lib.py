@@ -22,6 +22,11 @@ SIGNATURES = {
     "vqhip_set_local_omegas": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vqhip_set_kernel_policy": (C.c_int, [_v, C.c_int]),
     "vqhip_assign": (C.c_int, [_v, _f, C.c_uint64, _u, _f]),
+    "vqhip_assign_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), C.c_uint64, C.c_uint32, _u, _f]),
+    "vqhip_set_prototypes_f64": (C.c_int, [_v, C.POINTER(C.c_double), C.c_uint32, C.c_uint32]),
+    "vqhip_assign_f64": (C.c_int, [_v, C.POINTER(C.c_double), C.c_uint64, _u, C.POINTER(C.c_double)]),
+    "vqhip_assign_matched_f64": (C.c_int, [_v, C.POINTER(C.c_double), _u, C.c_uint64, _u, C.POINTER(C.c_double), _u,
+                                           C.POINTER(C.c_double)]),
     "vqhip_assign_device": (C.c_int, [_v, _v, C.c_uint64, _v, _v, _v]),
     "vqhip_assign_matched": (C.c_int, [_v, _f, _u, C.c_uint64, _u, _f, _u, _f]),
     "vqhip_assign_matched_device": (C.c_int, [_v, _v, _v, C.c_uint64, _v, _v, _v, _v, _v]),

@@ -113,6 +113,47 @@ class Context:
         self._chk(self._L.vqhip_assign(self._h, _fp(X), N, _up(idx), _fp(dist)))
         return idx, dist
 
+    def assign_rows(self, rows, want_dist: bool = True):
+        """`predict`'s own input shape: a sequence of separately allocated f64 rows (the reference's
+        `&Vec<Array1<f64>>`, src/vq/vq.rs:142).  Every row's length is asserted here, then the library
+        gathers and narrows them straight into its pinned upload buffers."""
+        rows = [np.ascontiguousarray(r, dtype=np.float64) for r in rows]
+        N = len(rows)
+        for r in rows:
+            if r.ndim != 1 or r.shape[0] != self.D:
+                raise ValueError(f"every row must hold {self.D} values")
+        ptrs = (C.POINTER(C.c_double) * max(N, 1))(*[r.ctypes.data_as(C.POINTER(C.c_double)) for r in rows])
+        idx = np.empty(N, dtype=np.uint32)
+        dist = np.empty(N, dtype=np.float32) if want_dist else None
+        self._chk(self._L.vqhip_assign_rows_f64(self._h, ptrs, N, self.D, _up(idx), _fp(dist)))
+        return idx, dist
+
+    # -- the Euclidean path in f64 (bit-exact against the reference's arithmetic)
+    def set_prototypes_f64(self, W):
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        if W.ndim != 2:
+            raise ValueError("prototypes must be K x D")
+        self._chk(self._L.vqhip_set_prototypes_f64(self._h, W.ctypes.data_as(C.POINTER(C.c_double)), W.shape[0],
+                                                   W.shape[1]))
+        self.K, self.D, self.M = W.shape[0], W.shape[1], 0
+
+    def assign_f64(self, X, y=None):
+        """-> (idx, dist) or, with class ids y, (jpos, dpos, jneg, dneg); dist in f64."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        self._check_shape(X.shape)
+        N = X.shape[0]
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        idx, dist = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.float64)
+        if y is None:
+            self._chk(self._L.vqhip_assign_f64(self._h, dp(X), N, _up(idx), dp(dist)))
+            return idx, dist
+        y = np.ascontiguousarray(y, dtype=np.uint32)
+        if y.shape != (N,):
+            raise ValueError("y must have one class id per sample")
+        jn, dn = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.float64)
+        self._chk(self._L.vqhip_assign_matched_f64(self._h, dp(X), _up(y), N, _up(idx), dp(dist), _up(jn), dp(dn)))
+        return idx, dist, jn, dn
+
     def assign_matched(self, X, y):
         """Both fit-time searches -> (jpos, dpos, jneg, dneg)."""
         if _is_torch(X):

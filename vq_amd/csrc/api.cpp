@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <new>
+#include <thread>
 
 #include "vq_common.h"
 
@@ -34,6 +36,7 @@ struct vqhip_ctx {
     std::vector<uint32_t> hcls;
 
     float *dW = nullptr;       // K x D
+    double *dW64 = nullptr;    // K x D in the reference's own number type (f64 entry points only)
     uint32_t *dcls = nullptr;  // K
     float *dOm = nullptr;      // M x D  or  K x M x D
     float *dP = nullptr;       // K x M: W . Omega^T (global Omega only)
@@ -198,13 +201,31 @@ int ensure_staging(vqhip_ctx *c, size_t chunk, bool matched)
 
 // Host-pointer path: pinned, double-buffered chunks.  While the GPU works on chunk c (stream
 // c%2) the CPU packs chunk c+1 into the other pinned buffer and unpacks the results of c-1.
-int run_host(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, uint32_t *o0, float *d0, uint32_t *o1,
+// Splits [0, n) over the host's cores (at most 16 workers: the GPU box gives one GPU 16 of them).
+void parallel_rows(uint64_t n, const std::function<void(uint64_t, uint64_t)> &fn)
+{
+    unsigned workers = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < 4096 || workers == 1) {
+        fn(0, n);
+        return;
+    }
+    const uint64_t per = (n + workers - 1) / workers;
+    std::vector<std::thread> pool;
+    for (unsigned w = 1; w < workers; ++w)
+        if (w * per < n) pool.emplace_back(fn, w * per, std::min<uint64_t>(n, (w + 1) * per));
+    fn(0, std::min<uint64_t>(n, per));
+    for (std::thread &t : pool) t.join();
+}
+
+// pack(dst, first_row, rows): writes rows [first_row, first_row + rows) as contiguous f32 into pinned dst.
+using Packer = std::function<void(float *, uint64_t, uint64_t)>;
+
+int run_host(vqhip_ctx *c, const Packer &pack, const uint32_t *y, uint64_t N, uint32_t *o0, float *d0, uint32_t *o1,
              float *d1)
 {
     if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
     if (y && c->hcls.empty()) return c->fail(VQHIP_ERR_STATE, "matched search needs vqhip_set_labels");
     if (N == 0) return VQHIP_OK;
-    if (!X) return c->fail(VQHIP_ERR_INVALID, "X is NULL");
     const size_t row = (size_t)c->D * sizeof(float);
     size_t chunk = std::max<size_t>(1024, (128ull << 20) / row);     // <= 128 MiB of samples per buffer
     chunk = (size_t)std::min<uint64_t>(chunk, N);
@@ -227,7 +248,7 @@ int run_host(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, uint32
         Staging &s = c->st[ci & 1];
         if (ci >= 2 && (rc = finish(ci - 2)) != VQHIP_OK) return rc;
         const uint64_t off = ci * chunk, n = std::min<uint64_t>(chunk, N - off);
-        std::memcpy(s.hX, X + off * c->D, n * row);
+        pack(s.hX, off, n);
         HIPCHK(c, hipMemcpyAsync(s.dX, s.hX, n * row, hipMemcpyHostToDevice, s.stream));
         if (y) {
             std::memcpy(s.hY, y + off, n * sizeof(uint32_t));
@@ -245,6 +266,60 @@ int run_host(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, uint32
     }
     for (uint64_t ci = nchunks >= 2 ? nchunks - 2 : 0; ci < nchunks; ++ci)
         if ((rc = finish(ci)) != VQHIP_OK) return rc;
+    return VQHIP_OK;
+}
+
+Packer contiguous_f32(const vqhip_ctx *c, const float *X)
+{
+    const uint32_t D = c->D;
+    return [X, D](float *dst, uint64_t first, uint64_t n) { std::memcpy(dst, X + first * D, n * D * sizeof(float)); };
+}
+
+// f64 Euclidean path (row f4): plain chunked copies, the scalar kernel instantiated for double.
+int run_host_f64(vqhip_ctx *c, const double *X, const uint32_t *y, uint64_t N, uint32_t *o0, double *d0, uint32_t *o1,
+                 double *d1)
+{
+    if (!c->dW64) return c->fail(VQHIP_ERR_STATE, "no f64 prototypes set (vqhip_set_prototypes_f64)");
+    if (y && c->hcls.empty()) return c->fail(VQHIP_ERR_STATE, "matched search needs vqhip_set_labels");
+    if (N == 0) return VQHIP_OK;
+    const uint32_t D = c->D;
+    const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1024, (64ull << 20) / (D * sizeof(double))));
+    double *dX = nullptr, *dD[2] = {nullptr, nullptr};
+    uint32_t *dY = nullptr, *dI[2] = {nullptr, nullptr};
+    int rc = VQHIP_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(dX); (void)hipFree(dY);
+        for (int j = 0; j < 2; ++j) { (void)hipFree(dD[j]); (void)hipFree(dI[j]); }
+    };
+#define F64CHK(call)                                  \
+    do {                                              \
+        hipError_t e_ = (call);                       \
+        if (e_ != hipSuccess) {                       \
+            rc = c->fail_hip(e_, #call);              \
+            cleanup();                                \
+            return rc;                                \
+        }                                             \
+    } while (0)
+    F64CHK(hipMalloc((void **)&dX, chunk * D * sizeof(double)));
+    F64CHK(hipMalloc((void **)&dY, chunk * sizeof(uint32_t)));
+    for (int j = 0; j < 2; ++j) {
+        F64CHK(hipMalloc((void **)&dD[j], chunk * sizeof(double)));
+        F64CHK(hipMalloc((void **)&dI[j], chunk * sizeof(uint32_t)));
+    }
+    for (uint64_t off = 0; off < N; off += chunk) {
+        const uint64_t n = std::min(chunk, N - off);
+        F64CHK(hipMemcpy(dX, X + off * D, n * D * sizeof(double), hipMemcpyHostToDevice));
+        if (y) F64CHK(hipMemcpy(dY, y + off, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        Outputs64 out{dI[0], dD[0], y ? dI[1] : nullptr, y ? dD[1] : nullptr};
+        F64CHK(launch_assign_scalar_f64(dX, n, D, c->dW64, c->K, c->dcls, y ? dY : nullptr, out, nullptr));
+        if (o0) F64CHK(hipMemcpy(o0 + off, dI[0], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (d0) F64CHK(hipMemcpy(d0 + off, dD[0], n * sizeof(double), hipMemcpyDeviceToHost));
+        if (y && o1) F64CHK(hipMemcpy(o1 + off, dI[1], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (y && d1) F64CHK(hipMemcpy(d1 + off, dD[1], n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+#undef F64CHK
+    cleanup();
+    c->last_kernel = "scalar_f64";
     return VQHIP_OK;
 }
 
@@ -303,6 +378,7 @@ int vqhip_destroy(vqhip_ctx *c)
     drop_engine(c);
     free_omega(c);
     (void)hipFree(c->dW);
+    (void)hipFree(c->dW64);
     (void)hipFree(c->dcls);
     (void)hipFree(c->dYproj);
     delete c;
@@ -325,6 +401,8 @@ int vqhip_set_prototypes(vqhip_ctx *c, const float *W, uint32_t K, uint32_t D)
     (void)hipFree(c->dcls);
     c->dcls = nullptr;
     c->hcls.clear();
+    (void)hipFree(c->dW64);
+    c->dW64 = nullptr;
     c->hW.assign(W, W + (size_t)K * D);
     c->K = K;
     c->D = D;
@@ -395,8 +473,31 @@ int vqhip_assign(vqhip_ctx *c, const float *X, uint64_t N, uint32_t *idx_out, fl
 {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && !idx_out) return c->fail(VQHIP_ERR_INVALID, "assign: idx_out is NULL");
+    if (N && !X) return c->fail(VQHIP_ERR_INVALID, "assign: X is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    return run_host(c, X, nullptr, N, idx_out, dist_out, nullptr, nullptr);
+    return run_host(c, contiguous_f32(c, X), nullptr, N, idx_out, dist_out, nullptr, nullptr);
+}
+
+int vqhip_assign_rows_f64(vqhip_ctx *c, const double *const *rows, uint64_t N, uint32_t D, uint32_t *idx_out,
+                          float *dist_out)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!rows || !idx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_rows_f64: rows or idx_out is NULL");
+    if (c->K && D != c->D) return c->fail(VQHIP_ERR_INVALID, "assign_rows_f64: D differs from the prototypes");
+    for (uint64_t i = 0; i < N; ++i)
+        if (!rows[i]) return c->fail(VQHIP_ERR_INVALID, "assign_rows_f64: a row pointer is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    // Vec<Array1<f64>> -> pinned contiguous f32, gathered and narrowed in one pass by the host cores
+    const Packer pack = [rows, D](float *dst, uint64_t first, uint64_t n) {
+        parallel_rows(n, [=](uint64_t a, uint64_t b) {
+            for (uint64_t i = a; i < b; ++i) {
+                const double *src = rows[first + i];
+                float *out = dst + i * D;
+                for (uint32_t d = 0; d < D; ++d) out[d] = (float)src[d];
+            }
+        });
+    };
+    return run_host(c, pack, nullptr, N, idx_out, dist_out, nullptr, nullptr);
 }
 
 int vqhip_assign_device(vqhip_ctx *c, const float *dX, uint64_t N, uint32_t *didx_out, float *ddist_out, void *stream)
@@ -411,9 +512,9 @@ int vqhip_assign_matched(vqhip_ctx *c, const float *X, const uint32_t *y, uint64
                          uint32_t *jneg, float *dneg)
 {
     if (!c) return VQHIP_ERR_INVALID;
-    if (N && !y) return c->fail(VQHIP_ERR_INVALID, "assign_matched: y is NULL");
+    if (N && (!y || !X)) return c->fail(VQHIP_ERR_INVALID, "assign_matched: X or y is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    return run_host(c, X, y, N, jpos, dpos, jneg, dneg);
+    return run_host(c, contiguous_f32(c, X), y, N, jpos, dpos, jneg, dneg);
 }
 
 int vqhip_assign_matched_device(vqhip_ctx *c, const float *dX, const uint32_t *dy, uint64_t N, uint32_t *djpos,
@@ -423,6 +524,35 @@ int vqhip_assign_matched_device(vqhip_ctx *c, const float *dX, const uint32_t *d
     if (N && (!dX || !dy)) return c->fail(VQHIP_ERR_INVALID, "assign_matched_device: dX or dy is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_device(c, dX, N, dy, Outputs{djpos, ddpos, djneg, ddneg}, (hipStream_t)stream);
+}
+
+int vqhip_set_prototypes_f64(vqhip_ctx *c, const double *W, uint32_t K, uint32_t D)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!W || K == 0 || D == 0) return c->fail(VQHIP_ERR_INVALID, "set_prototypes_f64: W is NULL or K/D is 0");
+    // the f32 model is set from the narrowed values, so both paths describe the same prototypes
+    std::vector<float> narrow((size_t)K * D);
+    for (size_t i = 0; i < narrow.size(); ++i) narrow[i] = (float)W[i];
+    int rc = vqhip_set_prototypes(c, narrow.data(), K, D);
+    if (rc != VQHIP_OK) return rc;
+    return upload(c, &c->dW64, W, (size_t)K * D);
+}
+
+int vqhip_assign_f64(vqhip_ctx *c, const double *X, uint64_t N, uint32_t *idx_out, double *dist_out)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!X || !idx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_f64: X or idx_out is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_host_f64(c, X, nullptr, N, idx_out, dist_out, nullptr, nullptr);
+}
+
+int vqhip_assign_matched_f64(vqhip_ctx *c, const double *X, const uint32_t *y, uint64_t N, uint32_t *jpos, double *dpos,
+                             uint32_t *jneg, double *dneg)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!X || !y)) return c->fail(VQHIP_ERR_INVALID, "assign_matched_f64: X or y is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_host_f64(c, X, y, N, jpos, dpos, jneg, dneg);
 }
 
 int vqhip_synth_fill_device(vqhip_ctx *c, float *dout, uint64_t count, uint64_t first, uint64_t seed,

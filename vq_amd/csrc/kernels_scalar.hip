@@ -19,11 +19,12 @@ namespace vq {
 
 namespace {
 
-struct Best {
-    float d;
+template <class T>
+struct BestT {
+    T d;
     uint32_t i;
-    __device__ Best() : d(INFINITY), i(0u) {}                     // helpers.rs:58-59
-    __device__ void offer(float dist, uint32_t k)
+    __device__ BestT() : d((T)INFINITY), i(0u) {}                 // helpers.rs:58-59
+    __device__ void offer(T dist, uint32_t k)
     {
         if (dist < d) {                                           // helpers.rs:70 (strict; NaN never wins)
             d = dist;
@@ -32,8 +33,10 @@ struct Best {
     }
 };
 
-template <bool MATCHED>
-__device__ inline void store(const Outputs &out, uint64_t i, const Best &pos, const Best &neg)
+using Best = BestT<float>;
+
+template <bool MATCHED, class O, class B>
+__device__ inline void store(const O &out, uint64_t i, const B &pos, const B &neg)
 {
     if (out.idx) out.idx[i] = pos.i;
     if (out.dist) out.dist[i] = pos.d;
@@ -43,24 +46,26 @@ __device__ inline void store(const Outputs &out, uint64_t i, const Best &pos, co
     }
 }
 
-template <bool MATCHED>
+// T = float: the product path.  T = double: the reference's own number type (src/lib.rs:32), so
+// index AND distance can be compared bit for bit with the f64 oracle.
+template <bool MATCHED, class T, class O>
 __global__ void __launch_bounds__(256)
-k_assign_scalar(const float *__restrict__ X, uint64_t N, uint32_t D, const float *__restrict__ W, uint32_t K,
-                const uint32_t *__restrict__ cls, const uint32_t *__restrict__ y, int rooted, Outputs out)
+k_assign_scalar(const T *__restrict__ X, uint64_t N, uint32_t D, const T *__restrict__ W, uint32_t K,
+                const uint32_t *__restrict__ cls, const uint32_t *__restrict__ y, int rooted, O out)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
-        const float *x = X + i * D;
+        const T *x = X + i * D;
         const uint32_t label = MATCHED ? y[i] : 0u;
-        Best pos, neg;
+        BestT<T> pos, neg;
         for (uint32_t k = 0; k < K; ++k) {
-            const float *w = W + (size_t)k * D;
-            float sum = 0.0f;
+            const T *w = W + (size_t)k * D;
+            T sum = (T)0;
             for (uint32_t d = 0; d < D; ++d) {
-                const float diff = w[d] - x[d];                   // helpers.rs:19 (prototype - sample)
+                const T diff = w[d] - x[d];                       // helpers.rs:19 (prototype - sample)
                 sum += diff * diff;
             }
-            const float dist = rooted ? sqrtf(sum) : sum;         // helpers.rs:23 / :44
+            const T dist = rooted ? (T)sqrt(sum) : sum;           // helpers.rs:23 / :44 (sqrt: correctly rounded)
             if (!MATCHED || cls[k] == label) pos.offer(dist, k);  // helpers.rs:113
             else neg.offer(dist, k);                              // helpers.rs:122
         }
@@ -127,11 +132,24 @@ hipError_t launch_assign_scalar(const float *dX, uint64_t N, uint32_t D, const f
 {
     if (N == 0) return hipSuccess;
     if (dy)
-        hipLaunchKernelGGL(k_assign_scalar<true>, dim3(grid_for(N)), dim3(256), 0, s, dX, N, D, dW, K, dcls, dy,
-                           (int)rooted, out);
+        hipLaunchKernelGGL((k_assign_scalar<true, float, Outputs>), dim3(grid_for(N)), dim3(256), 0, s, dX, N, D, dW, K,
+                           dcls, dy, (int)rooted, out);
     else
-        hipLaunchKernelGGL(k_assign_scalar<false>, dim3(grid_for(N)), dim3(256), 0, s, dX, N, D, dW, K, dcls, dy,
-                           (int)rooted, out);
+        hipLaunchKernelGGL((k_assign_scalar<false, float, Outputs>), dim3(grid_for(N)), dim3(256), 0, s, dX, N, D, dW, K,
+                           dcls, dy, (int)rooted, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_assign_scalar_f64(const double *dX, uint64_t N, uint32_t D, const double *dW, uint32_t K,
+                                    const uint32_t *dcls, const uint32_t *dy, Outputs64 out, hipStream_t s)
+{
+    if (N == 0) return hipSuccess;
+    if (dy)
+        hipLaunchKernelGGL((k_assign_scalar<true, double, Outputs64>), dim3(grid_for(N)), dim3(256), 0, s, dX, N, D, dW,
+                           K, dcls, dy, 1, out);
+    else
+        hipLaunchKernelGGL((k_assign_scalar<false, double, Outputs64>), dim3(grid_for(N)), dim3(256), 0, s, dX, N, D, dW,
+                           K, dcls, dy, 1, out);
     return hipGetLastError();
 }
 

@@ -39,11 +39,18 @@ struct Outputs {           // any pointer may be null
     uint32_t *jneg; float *dneg;       // non-matching search (matched calls only)
 };
 
+struct Outputs64 {         // the f64 instantiation of the Euclidean scalar kernel
+    uint32_t *idx;  double *dist;
+    uint32_t *jneg; double *dneg;
+};
+
 // ---------------------------------------------------------------- scalar kernels (kernels_scalar.hip)
 // X: N x D (ld = D).  Direct (x-w)^2 form, sums in index order, strict '<' from (0, +INF).
 hipError_t launch_assign_scalar(const float *dX, uint64_t N, uint32_t D, const float *dW, uint32_t K,
                                 const uint32_t *dcls, const uint32_t *dy, bool rooted, Outputs out,
                                 hipStream_t s);
+hipError_t launch_assign_scalar_f64(const double *dX, uint64_t N, uint32_t D, const double *dW, uint32_t K,
+                                    const uint32_t *dcls, const uint32_t *dy, Outputs64 out, hipStream_t s);
 // Y[i][m] = sum_d Om[m][d] * X[i][d]
 hipError_t launch_project_scalar(const float *dX, uint64_t N, uint32_t D, const float *dOm, uint32_t M,
                                  float *dY, hipStream_t s);
