@@ -7,7 +7,9 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unuse
 OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_mfma.o $(CSRC)/synth.o
 LIB      := vq_amd/libvqhip.so
 
-all: $(LIB) oracle
+MODELS_TEST := tests/cpp/test_models
+
+all: $(LIB) oracle $(MODELS_TEST)
 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
@@ -18,11 +20,15 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vq_common.h include/vqhip.h
 $(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/vq_common.h include/vqhip.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
+# the C++ host mirror (include/vq_models.hpp) with its tests; plain g++ against the C ABI
+$(MODELS_TEST): tests/cpp/test_models.cpp include/vq_models.hpp include/vqhip.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ -Lvq_amd -lvqhip -Wl,-rpath,'$$ORIGIN/../../vq_amd'
+
 oracle:
 	$(MAKE) -C oracle -s libvqoracle.so
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(MODELS_TEST)
 	$(MAKE) -C oracle -s clean
 
 .PHONY: all oracle clean

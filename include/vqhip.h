@@ -119,6 +119,19 @@ int vqhip_assign_matched_device(vqhip_ctx *ctx, const float *dX, const uint32_t 
                                 uint32_t *djpos, float *ddpos, uint32_t *djneg, float *ddneg,
                                 void *stream);
 
+/* ---- projections ---------------------------------------------------------
+ * project / project_omega for N samples.  X is N x D, row-major.
+ *   VQHIP_PROJECT_OMEGA   Y = Omega x,  N x M   LiRaMLVQ::project_omega   src/liramlvq/liramlvq.rs:429-446
+ *   VQHIP_PROJECT_LAMBDA  Y = Lambda x = Omega^T (Omega x),  N x D
+ *                                               GMLVQ::project     src/gmlvq/gmlvq.rs:354-372
+ *                                               LiRaMLVQ::project  src/liramlvq/liramlvq.rs:401-419
+ *                         with local Omegas: Y_i = Lambda_j x_i, j = nearest local prototype of x_i
+ *                                               LGMLVQ::project    src/lgmlvq/lgmlvq.rs:372-393
+ * Scalar kernels in this round (L2-bound); the MFMA form is the projection stage the search already has. */
+typedef enum { VQHIP_PROJECT_OMEGA = 0, VQHIP_PROJECT_LAMBDA = 1 } vqhip_projection;
+int vqhip_project(vqhip_ctx *ctx, const float *X, uint64_t N, int which /* vqhip_projection */, float *Y);
+int vqhip_project_device(vqhip_ctx *ctx, const float *dX, uint64_t N, int which, float *dY, void *stream);
+
 /* ---- the Euclidean path in the reference's own number type ------------
  * euclidean_distance + find_closest_prototype{,_matched} in f64 (src/helpers.rs:11-24, 55-77, 91-132):
  * the same operations in the same order as the reference (index-order sum, separate multiply and

@@ -376,3 +376,47 @@ def test_assign_rows_f64_equals_contiguous_f32(ctx):
     assert i2.shape == (0,)
     with pytest.raises(ValueError):
         ctx.assign_rows([np.zeros(128), np.zeros(127)])          # ragged row (src/helpers.rs:14)
+
+
+# ------------------------------------------------------------------ projections
+
+def _rel_err(got, want):
+    scale = np.maximum(np.abs(want).max(axis=1, keepdims=True), 1e-30)     # per row: entries can cancel to ~0
+    return float((np.abs(got - want) / scale).max())
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[6] == "global"], ids=lambda s: s[0])
+def test_project_global(ctx, shape):
+    from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
+    m = _model(shape)
+    X = synth.samples_host(m, 0, m.cfg.N)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    synth.load_model(ctx, m, with_labels=False)
+    Y = ctx.project(X, PROJECT_LAMBDA)                                    # gmlvq.rs:354-372
+    assert Y.shape == X.shape
+    assert _rel_err(Y, oracle.project_lambda(m.omega, X)) < 1e-5
+    Z = ctx.project(X, PROJECT_OMEGA)                                     # liramlvq.rs:429-446
+    assert Z.shape == (m.cfg.N, m.cfg.M)
+    assert _rel_err(Z, oracle.project_omega(m.omega, X)) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[6] == "local"], ids=lambda s: s[0])
+def test_project_local(ctx, shape):
+    from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
+    m = _model(shape)
+    X = synth.samples_host(m, 0, m.cfg.N)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    synth.load_model(ctx, m, with_labels=False)
+    Y = ctx.project(X, PROJECT_LAMBDA)                                    # lgmlvq.rs:372-393
+    win, best, second = oracle.assign(X, m.W, omega=m.omega, threads=8)
+    om = np.asarray(m.omega, dtype=np.float64)
+    want = np.stack([om[j].T @ (om[j] @ x.astype(np.float64)) for j, x in zip(win, X)])
+    clear = (second - best) / np.maximum(best, 1e-300) > 1e-5              # near-tied winners may differ
+    assert _rel_err(Y[clear], want[clear]) < 1e-5
+    with pytest.raises(VqhipError) as e:
+        ctx.project(X, PROJECT_OMEGA)
+    assert e.value.code == -5
+    ctx.set_prototypes(m.W)                                               # Euclidean model: nothing to project with
+    with pytest.raises(VqhipError) as e:
+        ctx.project(X, PROJECT_LAMBDA)
+    assert e.value.code == -2

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libvqhip.so")
 
 OK, ERR_INVALID, ERR_STATE, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA = 0, 1, 2
+PROJECT_OMEGA, PROJECT_LAMBDA = 0, 1
 
 # name -> (restype, argtypes); the single list the symbol-export test walks too
 _f, _u, _v = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
@@ -23,6 +24,8 @@ SIGNATURES = {
     "vqhip_set_kernel_policy": (C.c_int, [_v, C.c_int]),
     "vqhip_assign": (C.c_int, [_v, _f, C.c_uint64, _u, _f]),
     "vqhip_assign_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), C.c_uint64, C.c_uint32, _u, _f]),
+    "vqhip_project": (C.c_int, [_v, _f, C.c_uint64, C.c_int, _f]),
+    "vqhip_project_device": (C.c_int, [_v, _v, C.c_uint64, C.c_int, _v, _v]),
     "vqhip_set_prototypes_f64": (C.c_int, [_v, C.POINTER(C.c_double), C.c_uint32, C.c_uint32]),
     "vqhip_assign_f64": (C.c_int, [_v, C.POINTER(C.c_double), C.c_uint64, _u, C.POINTER(C.c_double)]),
     "vqhip_assign_matched_f64": (C.c_int, [_v, C.POINTER(C.c_double), _u, C.c_uint64, _u, C.POINTER(C.c_double), _u,

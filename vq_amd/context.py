@@ -128,6 +128,15 @@ class Context:
         self._chk(self._L.vqhip_assign_rows_f64(self._h, ptrs, N, self.D, _up(idx), _fp(dist)))
         return idx, dist
 
+    def project(self, X, which: int = _lib.PROJECT_LAMBDA):
+        """project (Lambda x, N x D) / project_omega (Omega x, N x M); local Omegas use the winner's Lambda_j."""
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        self._check_shape(X.shape)
+        width = self.M if which == _lib.PROJECT_OMEGA else self.D
+        Y = np.empty((X.shape[0], width), dtype=np.float32)
+        self._chk(self._L.vqhip_project(self._h, _fp(X), X.shape[0], int(which), _fp(Y)))
+        return Y
+
     # -- the Euclidean path in f64 (bit-exact against the reference's arithmetic)
     def set_prototypes_f64(self, W):
         W = np.ascontiguousarray(W, dtype=np.float64)

@@ -40,6 +40,9 @@ struct vqhip_ctx {
     uint32_t *dcls = nullptr;  // K
     float *dOm = nullptr;      // M x D  or  K x M x D
     float *dP = nullptr;       // K x M: W . Omega^T (global Omega only)
+    float *dOmT = nullptr;     // D x M: Omega^T (global Omega only; second half of the Lambda projection)
+    float *dProj = nullptr;    // projection scratch: chunk x M intermediate, chunk x u32 winners
+    size_t dProj_cap = 0;
     float *dYproj = nullptr;   // scalar-path scratch: projected samples, chunk x M
     size_t dYproj_cap = 0;
 
@@ -101,6 +104,7 @@ void free_omega(vqhip_ctx *c)
 {
     (void)hipFree(c->dOm); c->dOm = nullptr;
     (void)hipFree(c->dP);  c->dP = nullptr;
+    (void)hipFree(c->dOmT); c->dOmT = nullptr;
     c->hOm.clear();
     c->M = 0;
     c->omega_kind = OMEGA_NONE;
@@ -269,6 +273,56 @@ int run_host(vqhip_ctx *c, const Packer &pack, const uint32_t *y, uint64_t N, ui
     return VQHIP_OK;
 }
 
+uint32_t project_width(const vqhip_ctx *c, int which) { return which == VQHIP_PROJECT_OMEGA ? c->M : c->D; }
+
+int check_project(vqhip_ctx *c, int which)
+{
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
+    if (c->omega_kind == OMEGA_NONE) return c->fail(VQHIP_ERR_STATE, "project needs vqhip_set_omega or vqhip_set_local_omegas");
+    if (which != VQHIP_PROJECT_OMEGA && which != VQHIP_PROJECT_LAMBDA) return c->fail(VQHIP_ERR_INVALID, "unknown projection");
+    if (c->omega_kind == OMEGA_LOCAL && which == VQHIP_PROJECT_OMEGA)
+        return c->fail(VQHIP_ERR_UNSUPPORTED, "local Omegas project with Lambda_j only (src/lgmlvq/lgmlvq.rs:372-393)");
+    return VQHIP_OK;
+}
+
+// One device-resident batch of project / project_omega, enqueued on `s`.
+int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *dY, hipStream_t s)
+{
+    int rc = check_project(c, which);
+    if (rc != VQHIP_OK || N == 0) return rc;
+    if (c->omega_kind == OMEGA_GLOBAL && which == VQHIP_PROJECT_OMEGA) {          // liramlvq.rs:429-446
+        HIPCHK(c, launch_project_scalar(dX, N, c->D, c->dOm, c->M, dY, s));
+        return VQHIP_OK;
+    }
+    // Lambda x = Omega^T (Omega x): chunks of rows through an N x M intermediate (+ the winners, local case)
+    const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (64ull << 20) / ((c->M + 1) * 4ull)));
+    const size_t need = (size_t)chunk * (c->M + 1);
+    if (c->dProj_cap < need) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        (void)hipFree(c->dProj);
+        c->dProj = nullptr;
+        c->dProj_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->dProj, need * sizeof(float)));
+        c->dProj_cap = need;
+    }
+    float *dT = c->dProj;
+    uint32_t *dwin = (uint32_t *)(c->dProj + (size_t)chunk * c->M);
+    for (uint64_t off = 0; off < N; off += chunk) {
+        const uint64_t n = std::min(chunk, N - off);
+        const float *x = dX + off * c->D;
+        float *y = dY + off * c->D;
+        if (c->omega_kind == OMEGA_GLOBAL) {                                        // gmlvq.rs:354-372
+            HIPCHK(c, launch_project_scalar(x, n, c->D, c->dOm, c->M, dT, s));
+            HIPCHK(c, launch_project_scalar(dT, n, c->M, c->dOmT, c->D, y, s));
+        } else {                                                                    // lgmlvq.rs:372-393
+            rc = run_device(c, x, n, nullptr, Outputs{dwin, nullptr, nullptr, nullptr}, s);
+            if (rc != VQHIP_OK) return rc;
+            HIPCHK(c, launch_project_local(x, n, c->D, c->dOm, c->M, dwin, dT, y, s));
+        }
+    }
+    return VQHIP_OK;
+}
+
 Packer contiguous_f32(const vqhip_ctx *c, const float *X)
 {
     const uint32_t D = c->D;
@@ -381,6 +435,7 @@ int vqhip_destroy(vqhip_ctx *c)
     (void)hipFree(c->dW64);
     (void)hipFree(c->dcls);
     (void)hipFree(c->dYproj);
+    (void)hipFree(c->dProj);
     delete c;
     return VQHIP_OK;
 }
@@ -442,7 +497,12 @@ int vqhip_set_omega(vqhip_ctx *c, const float *Om, uint32_t M, uint32_t D)
             for (uint32_t d = 0; d < D; ++d) t += (double)Om[(size_t)m * D + d] * (double)c->hW[(size_t)k * D + d];
             P[(size_t)k * M + m] = (float)t;
         }
-    return upload(c, &c->dP, P.data(), P.size());
+    rc = upload(c, &c->dP, P.data(), P.size());
+    if (rc != VQHIP_OK) return rc;
+    std::vector<float> OmT((size_t)D * M);
+    for (uint32_t m = 0; m < M; ++m)
+        for (uint32_t d = 0; d < D; ++d) OmT[(size_t)d * M + m] = Om[(size_t)m * D + d];
+    return upload(c, &c->dOmT, OmT.data(), OmT.size());
 }
 
 int vqhip_set_local_omegas(vqhip_ctx *c, const float *Oms, uint32_t K, uint32_t M, uint32_t D)
@@ -524,6 +584,38 @@ int vqhip_assign_matched_device(vqhip_ctx *c, const float *dX, const uint32_t *d
     if (N && (!dX || !dy)) return c->fail(VQHIP_ERR_INVALID, "assign_matched_device: dX or dy is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_device(c, dX, N, dy, Outputs{djpos, ddpos, djneg, ddneg}, (hipStream_t)stream);
+}
+
+int vqhip_project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *dY, void *stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!dX || !dY)) return c->fail(VQHIP_ERR_INVALID, "project_device: dX or dY is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return project_device(c, dX, N, which, dY, (hipStream_t)stream);
+}
+
+int vqhip_project(vqhip_ctx *c, const float *X, uint64_t N, int which, float *Y)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!X || !Y)) return c->fail(VQHIP_ERR_INVALID, "project: X or Y is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = check_project(c, which);
+    if (rc != VQHIP_OK || N == 0) return rc;
+    const uint32_t D = c->D, Wd = project_width(c, which);
+    const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1024, (64ull << 20) / (std::max(D, Wd) * 4ull)));
+    float *dX = nullptr, *dY = nullptr;
+    hipError_t e = hipMalloc((void **)&dX, chunk * D * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&dY, chunk * Wd * sizeof(float));
+    for (uint64_t off = 0; off < N && e == hipSuccess && rc == VQHIP_OK; off += chunk) {
+        const uint64_t n = std::min(chunk, N - off);
+        e = hipMemcpy(dX, X + off * D, n * D * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) rc = project_device(c, dX, n, which, dY, nullptr);
+        if (e == hipSuccess && rc == VQHIP_OK) e = hipMemcpy(Y + off * Wd, dY, n * Wd * sizeof(float), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(dX);
+    (void)hipFree(dY);
+    if (e != hipSuccess) return c->fail_hip(e, "vqhip_project");
+    return rc;
 }
 
 int vqhip_set_prototypes_f64(vqhip_ctx *c, const double *W, uint32_t K, uint32_t D)

@@ -117,6 +117,42 @@ k_assign_local_scalar(const float *__restrict__ X, uint64_t N, uint32_t D, const
     }
 }
 
+// LGMLVQ::project (src/lgmlvq/lgmlvq.rs:372-393): sample i is projected with the Omega of its nearest
+// prototype j = idx[i].  T[i][m] = Omega_j[m] . x_i, then Y[i][d] = sum_m Omega_j[m][d] T[i][m] = (Lambda_j x_i)[d].
+__global__ void __launch_bounds__(256)
+k_project_local_fwd(const float *__restrict__ X, uint64_t N, uint32_t D, const float *__restrict__ Oms, uint32_t M,
+                    const uint32_t *__restrict__ idx, float *__restrict__ T)
+{
+    const uint64_t total = N * M;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const uint64_t i = e / M;
+        const uint32_t m = (uint32_t)(e % M);
+        const float *x = X + i * D;
+        const float *o = Oms + ((size_t)idx[i] * M + m) * D;
+        float t = 0.0f;
+        for (uint32_t d = 0; d < D; ++d) t += o[d] * x[d];
+        T[e] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_project_local_bwd(const float *__restrict__ T, uint64_t N, uint32_t D, const float *__restrict__ Oms, uint32_t M,
+                    const uint32_t *__restrict__ idx, float *__restrict__ Y)
+{
+    const uint64_t total = N * D;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const uint64_t i = e / D;
+        const uint32_t d = (uint32_t)(e % D);
+        const float *t = T + i * M;
+        const float *o = Oms + (size_t)idx[i] * M * D + d;
+        float y = 0.0f;
+        for (uint32_t m = 0; m < M; ++m) y += o[(size_t)m * D] * t[m];
+        Y[e] = y;
+    }
+}
+
 inline unsigned grid_for(uint64_t work)
 {
     uint64_t blocks = (work + 255) / 256;
@@ -158,6 +194,15 @@ hipError_t launch_project_scalar(const float *dX, uint64_t N, uint32_t D, const 
 {
     if (N == 0) return hipSuccess;
     hipLaunchKernelGGL(k_project_scalar, dim3(grid_for(N * M)), dim3(256), 0, s, dX, N, D, dOm, M, dY);
+    return hipGetLastError();
+}
+
+hipError_t launch_project_local(const float *dX, uint64_t N, uint32_t D, const float *dOms, uint32_t M,
+                                const uint32_t *didx, float *dT, float *dY, hipStream_t s)
+{
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_project_local_fwd, dim3(grid_for(N * M)), dim3(256), 0, s, dX, N, D, dOms, M, didx, dT);
+    hipLaunchKernelGGL(k_project_local_bwd, dim3(grid_for(N * D)), dim3(256), 0, s, dT, N, D, dOms, M, didx, dY);
     return hipGetLastError();
 }
 

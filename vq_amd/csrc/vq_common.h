@@ -54,6 +54,9 @@ hipError_t launch_assign_scalar_f64(const double *dX, uint64_t N, uint32_t D, co
 // Y[i][m] = sum_d Om[m][d] * X[i][d]
 hipError_t launch_project_scalar(const float *dX, uint64_t N, uint32_t D, const float *dOm, uint32_t M,
                                  float *dY, hipStream_t s);
+// LGMLVQ::project: Y[i] = Omega_j^T (Omega_j x_i) with j = didx[i]; dT is N x M scratch
+hipError_t launch_project_local(const float *dX, uint64_t N, uint32_t D, const float *dOms, uint32_t M,
+                                const uint32_t *didx, float *dT, float *dY, hipStream_t s);
 // dist_j = sum_m ( sum_d Om_j[m][d] * (x[d] - w_j[d]) )^2
 hipError_t launch_assign_local_scalar(const float *dX, uint64_t N, uint32_t D, const float *dW, uint32_t K,
                                       const float *dOms, uint32_t M, const uint32_t *dcls,
