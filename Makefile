@@ -3,7 +3,9 @@
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     := gfx950
 CSRC     := vq_amd/csrc
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wextra -Wno-unused-parameter -Iinclude
+# atomic optimizer off: it turns a one-lane returning atomic into atomic + immediate readfirstlane, i.e. a
+# wait for the atomic's round trip right where it is issued (k_resident_pipe claims its batches ahead of time)
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -mllvm -amdgpu-atomic-optimizer-strategy=None -Wall -Wextra -Wno-unused-parameter -Iinclude
 OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_mfma.o $(CSRC)/synth.o
 LIB      := vq_amd/libvqhip.so
 

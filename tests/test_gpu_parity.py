@@ -83,6 +83,8 @@ SHAPES = [
     ("glvq_128x256", "GLVQ", 4099, 128, 256, 0, "none"),
     ("glvq_ragged_d100_k37", "GLVQ", 777, 100, 37, 0, "none"),
     ("glvq_d64_k70", "GLVQ", 1500, 64, 70, 0, "none"),
+    ("glvq_streamed_k600", "GLVQ", 2500, 128, 600, 0, "none"),       # image larger than LDS: k_engine
+    ("glvq_streamed_d256", "GLVQ", 1200, 256, 300, 0, "none"),
     ("gmlvq_128x128", "GMLVQ", 2051, 128, 256, 128, "global"),
     ("gmlvq_small_d12", "GMLVQ", 500, 12, 9, 12, "global"),
     ("liramlvq_r16_d256", "LiRaMLVQ", 1111, 256, 128, 16, "global"),
@@ -95,7 +97,7 @@ SHAPES = [
 # kernel family VQHIP_KERNEL_AUTO must pick per shape (the engine serves D % 4 == 0, D <= 256)
 AUTO_KERNEL = {
     "c1_vq_iris_shape": "mfma_euclid", "glvq_128x256": "mfma_euclid", "glvq_ragged_d100_k37": "mfma_euclid",
-    "glvq_d64_k70": "mfma_euclid", "gmlvq_128x128": "mfma_omega", "gmlvq_small_d12": "mfma_omega",
+    "glvq_d64_k70": "mfma_euclid", "glvq_streamed_k600": "mfma_euclid", "glvq_streamed_d256": "mfma_euclid", "gmlvq_128x128": "mfma_omega", "gmlvq_small_d12": "mfma_omega",
     "liramlvq_r16_d256": "mfma_omega", "liramlvq_r3_d20": "mfma_omega", "lgmlvq_8x128": "mfma_local",
     "lgmlvq_small": "scalar",      # D = 10 is not a multiple of 4
 }

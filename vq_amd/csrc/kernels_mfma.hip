@@ -48,9 +48,8 @@ struct EngineArgs {
     uint64_t nbatches;
     Outputs out;
     float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
-    int stagger;              // experiment: 1 = upper half of the grid starts late, 2 = odd workgroups
-    int stagger_sleeps;
-    unsigned long long *dbg;  // diagnostic build (ABL & 4): per-wave cycle sums of the loop phases
+    uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
+    unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
 };
 
 namespace {
@@ -132,6 +131,38 @@ struct Best1 {
     }
 };
 
+// ---- packed screening keys (what they are and why: the comment above k_resident_pipe)
+struct Keys2 {                       // unlabelled search: best two keys and their tiles
+    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, t1 = 0u, t2 = 0u;
+};
+struct KeysM {                       // labelled search: best key with cls == y, best with cls != y
+    uint32_t p = 0xFFFFFFFFu, n = 0xFFFFFFFFu, tp = 0u, tn = 0u;
+};
+constexpr uint32_t KEY_VALID_BELOW = 0x7F800000u;   // keys of finite non-negative scores
+
+__device__ __forceinline__ uint32_t pack_key(float score, uint32_t o)
+{
+    uint32_t key;                                   // (bits & ~15) | o in one instruction
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(score), "s"(0xFFFFFFF0u), "n"(o));
+    return key;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ uint32_t key_row(uint32_t key, uint32_t tile, int h)   // prototype index of a key
+{
+    const uint32_t o = key & 15u;
+    return tile * 32u + ((o >> 2) << 3) + (o & 3u) + 4u * (uint32_t)h;
+}
+
+__device__ __forceinline__ bool keyless(uint32_t ak, uint32_t ai, uint32_t bk, uint32_t bi)
+{
+    return ak < bk || (ak == bk && ai < bi);
+}
+
 // LDS-DMA of one stage (BYTES, multiple of 16) from its pre-swizzled global image: a linear copy,
 // 1 KiB per wave-instruction, pieces dealt round-robin to the 4 waves.
 template <int BYTES>
@@ -150,7 +181,8 @@ __device__ __forceinline__ void stage_group(char *lds_dst, const char *gsrc, int
 
 // acc[s] (+)= tile . xf[s]^T for one 32-row tile in LDS; accumulators start at the tile's init column.
 template <int R, int S>
-__device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S][R / 8], f32x16 (&acc)[S], int row, int h)
+__device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S][R / 8], f32x16 (&acc)[S], const float (&shift)[S],
+                                         int row, int h)
 {
     using Gm = Geom<R>;
     const float *tail = tile + Gm::W_FLOATS;
@@ -159,8 +191,8 @@ __device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S]
         const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
-            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
+            acc[s][4 * g + 0] = ci[0] + shift[s]; acc[s][4 * g + 1] = ci[1] + shift[s];
+            acc[s][4 * g + 2] = ci[2] + shift[s]; acc[s][4 * g + 3] = ci[3] + shift[s];
         }
     }
     const float *rowp = tile + Gm::chunk_off(row, h);
@@ -214,7 +246,15 @@ __device__ __forceinline__ void exact_scan(const f32x4 (&xf)[R / 8], const float
 
 // ------------------------------------------------------------------------------ the kernel
 // R1: padded sample length.  R2: padded projected length (OMEGA only).  S: sample tiles per wave.
-template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, int ABL = 0>
+//
+// Batches (4 waves x S tiles x 32 samples) are claimed by the workgroup from a global counter: the two
+// workgroups of a CU do not get equal shares of the matrix pipes, so a fixed split leaves half the
+// waves of the chip running alone at the end.  Thread 0 claims the next batch at the top of a batch;
+// one barrier publishes it.  OMEGA: the samples are dead once they are
+// projected, so the next batch's rows are fetched into the same registers while the search runs
+// (every workgroup of the chip loading, then computing, in lockstep is an HBM burst followed by HBM
+// silence).  The search stages screen with packed keys (4 VALU per score, see k_resident_pipe).
+template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS>
 __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const uint32_t *__restrict__ cls_plain)
 {
     using G1 = Geom<R1>;
@@ -226,6 +266,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
     constexpr int T1 = R2 >= 32 ? R2 / 32 : 1;
     constexpr int NG1 = (T1 + G1::G - 1) / G1::G;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+    __shared__ uint32_t claimed;                                     // the batch after this one
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s_col = lane & 31, h = lane >> 5;
@@ -241,35 +282,15 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
             stage_group<G1::STAGE_BYTES>(dst, (const char *)(a.img1 + (size_t)q * G1::STAGE_FLOATS), wave, lane);
     };
 
-    if ((a.stagger == 1 && blockIdx.x >= gridDim.x / 2) || (a.stagger == 2 && (blockIdx.x & 1)))
-        for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-    unsigned long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto lap = [&](int slot) {                        // diagnostic build only
-        if (ABL & 4) {
-            const unsigned long long t = stamp();
-            tm[slot] += t - tprev;
-            tprev = t;
-        }
-    };
-    if (ABL & 4) tprev = stamp();
-    int cur = 0;
-    if ((uint64_t)blockIdx.x < a.nbatches) {
-        issue(0, 0);
-        __syncthreads();                                             // waits vmcnt(0) for the DMA, then barrier
-    }
-
-    for (uint64_t b = blockIdx.x; b < a.nbatches; b += gridDim.x) {
-        const bool last_batch = b + gridDim.x >= a.nbatches;
-
-        // ---- this wave's S tiles of 32 samples -> B fragments (straight from HBM, 16 B per lane)
-        f32x4 xf[S][R1 / 8];
-        uint64_t sample[S];
-        uint32_t label[S];
+    // this wave's S tiles of 32 samples of batch bb -> B fragments (straight from HBM, 16 B per lane)
+    f32x4 xf[S][R1 / 8];
+    uint32_t label[S];
+    auto load_samples = [&](uint64_t bb) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            sample[s] = ((b * 4 + wave) * S + s) * 32 + s_col;
-            const bool live = sample[s] < a.N;
-            const float *xrow = a.X + sample[s] * a.D;
+            const uint64_t smp = ((bb * 4 + wave) * S + s) * 32 + s_col;
+            const bool live = bb < a.nbatches && smp < a.N;
+            const float *xrow = a.X + smp * a.D;
 #pragma unroll
             for (int j = 0; j < R1 / 8; ++j) {
                 const uint32_t c = 2 * j + h;
@@ -277,15 +298,42 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                 const f32x4 v = *(const f32x4 *)(ok ? xrow + 4 * c : a.X);
                 xf[s][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            label[s] = (MATCHED && live) ? a.y[sample[s]] : 0u;
+            label[s] = (MATCHED && live) ? a.y[smp] : 0u;
+        }
+    };
+
+    int cur = 0;
+    uint64_t b = blockIdx.x;
+    if (b < a.nbatches) {
+        issue(0, 0);
+        load_samples(b);
+        __syncthreads();                                             // waits vmcnt(0) for the DMA, then barrier
+    }
+
+    while (b < a.nbatches) {
+        if (tid == 0) claimed = gridDim.x + atomicAdd(a.queue, 1u);
+        __syncthreads();
+        const uint64_t bnext = claimed;
+        uint64_t sample[S];
+        uint32_t lab[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sample[s] = ((b * 4 + wave) * S + s) * 32 + s_col;
+            lab[s] = label[s];
         }
 
         f32x4 yf[S][RS / 8];                                          // search-stage fragments
-        Top2 top[S];
-        Best1 pos[S], neg[S];
-        float dsum[S];
+        Keys2 ku[S];
+        KeysM km[S];
+        Best1 pos[S], neg[S];                                         // LOCAL: exact distances, offered in index order
+        float dsum[S], shift[S];
+        bool unsafe[S];
 #pragma unroll
-        for (int s = 0; s < S; ++s) dsum[s] = 0.0f;
+        for (int s = 0; s < S; ++s) {
+            dsum[s] = 0.0f;
+            shift[s] = 0.0f;
+            unsafe[s] = false;
+        }
         if (MODE != MODE_OMEGA) {
 #pragma unroll
             for (int s = 0; s < S; ++s)
@@ -300,14 +348,11 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
 
         // One step of the cyclic weight stream: prefetch the next stage, compute on this one, barrier.
         uint32_t q = 0;
-        lap(0);                                   // 0: sample loads issued (+ previous batch's stores)
         auto step = [&](auto &&compute) {
-            if (!(ABL & 2) && !(last_batch && q + 1 == ngroups)) issue(q + 1 == ngroups ? 0u : q + 1, cur ^ 1);
-            lap(1);                               // 1: DMA issue
-            compute((const float *)(smem + ((ABL & 2) ? 0 : cur) * BUF_BYTES));
-            lap(3);                               // 3: per-tile epilogue (2 = MFMA part, stamped inside)
-            if (!(ABL & 2)) __syncthreads();   // next stage landed (vmcnt(0)) and everyone is done reading this one
-            lap(4);                               // 4: barrier
+            const bool wrap = q + 1 == ngroups;
+            if (!(wrap && bnext >= a.nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);   // nothing to stage after the last batch
+            compute((const float *)(smem + cur * BUF_BYTES));
+            __syncthreads();                   // next stage landed (vmcnt(0)) and everyone is done reading this one
             cur ^= 1;
             ++q;
         };
@@ -320,7 +365,10 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     static_for<0, G1::G>([&](auto tt) {
                         constexpr int t = decltype(q1)::value * G1::G + decltype(tt)::value;
                         f32x16 acc[S];
-                        tile_mma<R1, S>(stage + decltype(tt)::value * G1::TILE_FLOATS, xf, acc, s_col, h);
+                        float zero[S];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) zero[s] = 0.0f;
+                        tile_mma<R1, S>(stage + decltype(tt)::value * G1::TILE_FLOATS, xf, acc, zero, s_col, h);
                         static_for<0, 4>([&](auto g) {
                             constexpr int jj = 4 * t + decltype(g)::value;
                             if constexpr (jj < RS / 8) {
@@ -332,6 +380,22 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     });
                 });
             });
+            load_samples(bnext);               // x is dead: the next batch's rows arrive while the search runs
+        }
+
+        if constexpr (MODE != MODE_LOCAL) {
+            // positivity shift of the screening scores: c = ||y||^2 (1 + 2^-8) + tiny (see k_resident_pipe)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int j = 0; j < RS / 8; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ss = fmaf(yf[s][j][e], yf[s][j][e], ss);
+                ss += xor32(ss);
+                unsafe[s] = !(ss < a.ss_limit);
+                shift[s] = unsafe[s] ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+            }
         }
 
         const uint32_t nsearch = MODE == MODE_OMEGA ? a.ngroups2 : a.ngroups1;
@@ -343,7 +407,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     for (int tt = 0; tt < G1::G; ++tt) {
                         const float *tile = stage + tt * G1::TILE_FLOATS;
                         f32x16 acc[S];
-                        tile_mma<R1, S>(tile, xf, acc, s_col, h);
+                        tile_mma<R1, S>(tile, xf, acc, shift, s_col, h);
                         const uint32_t ti = qs * G1::G + tt;
                         const uint32_t j = ti / a.tiles_per_proto, t = ti % a.tiles_per_proto;
 #pragma unroll
@@ -357,37 +421,56 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                                 const float total = dsum[s] + xor32(dsum[s]);
                                 dsum[s] = 0.0f;
                                 if (j < a.K) {                        // pad tiles past the last prototype never compete
-                                    if (!MATCHED || cj == label[s]) pos[s].offer(total, j);   // lgmlvq.rs:448 / :487
-                                    else neg[s].offer(total, j);                               // lgmlvq.rs:496
+                                    if (!MATCHED || cj == lab[s]) pos[s].offer(total, j);   // lgmlvq.rs:448 / :487
+                                    else neg[s].offer(total, j);                             // lgmlvq.rs:496
                                 }
                             }
                         }
                     }
                 } else {
-                    // ---- search stage: score = ||p_k||^2 - 2 y.p_k for 32 prototypes per tile
+                    // ---- search stage: key of ||p_k||^2 + c - 2 y.p_k for 32 prototypes per tile
 #pragma unroll
                     for (int tt = 0; tt < G2::G; ++tt) {
                         const float *tile = stage + tt * G2::TILE_FLOATS;
                         f32x16 acc[S];
-                        tile_mma<RS, S>(tile, yf, acc, s_col, h);
-                        lap(2);
-                        const uint32_t kbase = (qs * G2::G + tt) * 32 + 4 * h;
-                        const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32;
+                        tile_mma<RS, S>(tile, yf, acc, shift, s_col, h);
+                        const uint32_t tile_id = qs * G2::G + tt;
+                        const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32 + 4 * h;
+                        Keys2 ou[S];
+                        KeysM om[S];
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            u32x4 cg;
-                            if (MATCHED) cg = *(const u32x4 *)(tcls + 8 * g + 4 * h);
+                        for (int s = 0; s < S; ++s) {
+                            ou[s] = ku[s];
+                            om[s] = km[s];
+                        }
+                        static_for<0, 16>([&](auto oo) {
+                            constexpr int o = decltype(oo)::value;
+                            uint32_t cls = 0u;
+                            if (MATCHED) cls = tcls[8 * (o >> 2) + (o & 3)];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const uint32_t k = kbase + 8 * g + e;
-#pragma unroll
-                                for (int s = 0; s < S; ++s) {
-                                    const float v = acc[s][4 * g + e];
-                                    if (ABL & 1) top[s].b1 = fminf(top[s].b1, v);      // timing experiment only
-                                    else if (!MATCHED) top[s].offer(v, k);
-                                    else if (cg[e] == label[s]) pos[s].offer(v, k);       // helpers.rs:113
-                                    else neg[s].offer(v, k);                               // helpers.rs:122
+                            for (int s = 0; s < S; ++s) {
+                                const uint32_t key = pack_key(acc[s][o], o);
+                                if constexpr (!MATCHED) {
+                                    ku[s].b2 = umed3(ku[s].b1, ku[s].b2, key);
+                                    ku[s].b1 = ku[s].b1 < key ? ku[s].b1 : key;
+                                } else {
+                                    const bool match = cls == lab[s];                 // helpers.rs:113 / :122
+                                    const uint32_t kp = match ? key : 0xFFFFFFFFu, kn = match ? 0xFFFFFFFFu : key;
+                                    km[s].p = km[s].p < kp ? km[s].p : kp;
+                                    km[s].n = km[s].n < kn ? km[s].n : kn;
                                 }
+                            }
+                        });
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            if constexpr (!MATCHED) {
+                                const bool c1 = ku[s].b1 != ou[s].b1, c2 = ku[s].b2 != ou[s].b2;
+                                const uint32_t demoted = ku[s].b2 == ou[s].b1 ? ou[s].t1 : tile_id;
+                                ku[s].t2 = c1 ? demoted : (c2 ? tile_id : ou[s].t2);
+                                ku[s].t1 = c1 ? tile_id : ou[s].t1;
+                            } else {
+                                km[s].tp = km[s].p != om[s].p ? tile_id : om[s].tp;
+                                km[s].tn = km[s].n != om[s].n ? tile_id : om[s].tn;
                             }
                         }
                     }
@@ -395,7 +478,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
             });
         }
 
-        // ---- epilogue: lane pair (s, h=0/1) agrees on the winner, re-measures it exactly, stores
+        // ---- epilogue: lane pair (s, h=0/1) agrees on the candidates, re-measures them exactly, stores
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const bool live = sample[s] < a.N;
@@ -404,38 +487,49 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                 wp = pos[s];
                 wn = neg[s];
             } else {
-                bool rescan = false;
+                bool rescan = unsafe[s];
+                auto measure = [&](uint32_t k) {
+                    const float d = exact_sq<RS>(yf[s], a.plain, a.ldp, k, h);
+                    return ROOT ? sqrtf(d) : d;
+                };
                 if (!MATCHED) {
-                    top[s].merge_halves();
-                    const Top2 &t = top[s];
-                    if (t.b1 < INFINITY) {
-                        float d1 = exact_sq<RS>(yf[s], a.plain, a.ldp, t.i1, h);
-                        if (ROOT) d1 = sqrtf(d1);
-                        wp.d = d1; wp.i = t.i1;
-                        if (t.b2 < INFINITY) {
-                            float d2 = exact_sq<RS>(yf[s], a.plain, a.ldp, t.i2, h);
-                            if (ROOT) d2 = sqrtf(d2);
-                            if (lexless(d2, t.i2, d1, t.i1)) { wp.d = d2; wp.i = t.i2; }
+                    const uint32_t k1 = key_row(ku[s].b1, ku[s].t1, h), k2 = key_row(ku[s].b2, ku[s].t2, h);
+                    const uint32_t pb1 = xor32(ku[s].b1), pb2 = xor32(ku[s].b2), pk1 = xor32(k1), pk2 = xor32(k2);
+                    uint32_t f, fi, sd, si;                            // best two of the pair's four, by (key, index)
+                    if (keyless(pb1, pk1, ku[s].b1, k1)) {
+                        f = pb1; fi = pk1;
+                        if (keyless(ku[s].b1, k1, pb2, pk2)) { sd = ku[s].b1; si = k1; } else { sd = pb2; si = pk2; }
+                    } else {
+                        f = ku[s].b1; fi = k1;
+                        if (keyless(pb1, pk1, ku[s].b2, k2)) { sd = pb1; si = pk1; } else { sd = ku[s].b2; si = k2; }
+                    }
+                    if (f < KEY_VALID_BELOW && !rescan) {
+                        const float d1 = measure(fi);
+                        wp.d = d1; wp.i = fi;
+                        if (sd < KEY_VALID_BELOW) {
+                            const float d2 = measure(si);
+                            if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
                         }
-                        rescan = t.b1 == -INFINITY || !(wp.d < INFINITY);
+                        rescan = !(wp.d < INFINITY);
+                    } else {
+                        rescan = true;
                     }
                 } else {
-                    pos[s].merge_halves();
-                    neg[s].merge_halves();
-                    if (pos[s].d < INFINITY) {
-                        float d = exact_sq<RS>(yf[s], a.plain, a.ldp, pos[s].i, h);
-                        wp.d = ROOT ? sqrtf(d) : d; wp.i = pos[s].i;
-                        rescan |= pos[s].d == -INFINITY || !(wp.d < INFINITY);
+                    uint32_t kp = key_row(km[s].p, km[s].tp, h), kn = key_row(km[s].n, km[s].tn, h), p = km[s].p, n = km[s].n;
+                    const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
+                    if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
+                    if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
+                    if (p < KEY_VALID_BELOW) {
+                        wp.d = measure(kp); wp.i = kp;
+                        rescan |= !(wp.d < INFINITY);
                     }
-                    if (neg[s].d < INFINITY) {
-                        float d = exact_sq<RS>(yf[s], a.plain, a.ldp, neg[s].i, h);
-                        wn.d = ROOT ? sqrtf(d) : d; wn.i = neg[s].i;
-                        rescan |= neg[s].d == -INFINITY || !(wn.d < INFINITY);
+                    if (n < KEY_VALID_BELOW) {
+                        wn.d = measure(kn); wn.i = kn;
+                        rescan |= !(wn.d < INFINITY);
                     }
                 }
-                if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, cls_plain, MATCHED, label[s], wp, wn);
+                if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, cls_plain, MATCHED, lab[s], wp, wn);
             }
-            if (s == S - 1) lap(5);               // 5: batch epilogue (merge, exact re-measurement)
             if (live) {
                 if (h == 0) {
                     if (a.out.idx) a.out.idx[sample[s]] = wp.i;
@@ -446,10 +540,8 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                 }
             }
         }
-    }
-    if ((ABL & 4) && a.dbg && lane == 0) {
-        lap(6);
-        for (int i = 0; i < 8; ++i) a.dbg[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tm[i];
+        if (MODE != MODE_OMEGA) load_samples(bnext);
+        b = bnext;
     }
 }
 
@@ -479,7 +571,7 @@ __device__ __forceinline__ float exact_sq_lds(const f32x4 (&xf)[R / 8], const fl
     return p + xor32(p);
 }
 
-template <int R, int S, bool MATCHED, int ABL = 0>
+template <int R, int S, bool MATCHED>
 __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 {
     using Gm = Geom<R>;
@@ -522,11 +614,14 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
         }
         Top2 top[S];
         Best1 pos[S], neg[S];
+        float zero_shift[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) zero_shift[s] = 0.0f;
 
         for (uint32_t t = 0; t < ntiles; ++t) {
             const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
             f32x16 acc[S];
-            tile_mma<R, S>(tile, xf, acc, s_col, h);
+            tile_mma<R, S>(tile, xf, acc, zero_shift, s_col, h);
             const uint32_t kbase = t * 32 + 4 * h;
             const uint32_t *tcls = (const uint32_t *)(tile + Gm::W_FLOATS) + 32;
 #pragma unroll
@@ -539,8 +634,7 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         const float v = acc[s][4 * g + e];
-                        if (ABL & 1) top[s].b1 = fminf(top[s].b1, v);              // timing experiment only
-                        else if (!MATCHED) top[s].offer(v, k);
+                        if (!MATCHED) top[s].offer(v, k);
                         else if (cg[e] == label[s]) pos[s].offer(v, k);           // helpers.rs:113
                         else neg[s].offer(v, k);                                   // helpers.rs:122
                     }
@@ -620,32 +714,6 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 // across tiles, the lower k across the lane pair), NaN / -INF / pad-row (+INF) patterns sort above
 // every finite score, and the two candidates are re-measured exactly as before.  Samples whose
 // ||x||^2 is not safely finite go to the exact in-order scan.
-struct Keys2 {                       // unlabelled search: best two keys and their tiles
-    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, t1 = 0u, t2 = 0u;
-};
-struct KeysM {                       // labelled search: best key with cls == y, best with cls != y
-    uint32_t p = 0xFFFFFFFFu, n = 0xFFFFFFFFu, tp = 0u, tn = 0u;
-};
-constexpr uint32_t KEY_VALID_BELOW = 0x7F800000u;   // keys of finite non-negative scores
-
-__device__ __forceinline__ uint32_t pack_key(float score, uint32_t o)
-{
-    uint32_t key;                                   // (bits & ~15) | o in one instruction
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(score), "s"(0xFFFFFFF0u), "n"(o));
-    return key;
-}
-__device__ __forceinline__ uint32_t umed3(uint32_t x, uint32_t y, uint32_t z)
-{
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-    return r;
-}
-__device__ __forceinline__ uint32_t key_row(uint32_t key, uint32_t tile, int h)   // prototype index of a key
-{
-    const uint32_t o = key & 15u;
-    return tile * 32u + ((o >> 2) << 3) + (o & 3u) + 4u * (uint32_t)h;
-}
-
 // On entry:  acc = accumulator-init column of `tile` (+ c), a0 = this lane's chunk 0 of `tile`,
 //            prev = finished scores of tile number `tprev_id` (class ids in tprev's tail).
 // On exit:   acc = scores of (tile, xf), prev = init column of `next` (+ c), a0 = chunk 0 of `next`.
@@ -752,11 +820,6 @@ __device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tpr
     }
 }
 
-__device__ __forceinline__ bool keyless(uint32_t ak, uint32_t ai, uint32_t bk, uint32_t bi)
-{
-    return ak < bk || (ak == bk && ai < bi);
-}
-
 // Final step of a batch: the lane pair agrees on the candidates, re-measures them in the direct
 // (x - w)^2 form from the LDS image, roots, compares like helpers.rs:70.
 template <int R, bool MATCHED>
@@ -828,7 +891,6 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         }
     };
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
-    __shared__ uint32_t queue_head;                   // next unclaimed batch of this workgroup
     const unsigned long long r_entry = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
@@ -843,7 +905,6 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
                                                  (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
         }
-        if (threadIdx.x == 0) queue_head = 0u;
         __syncthreads();
     }
     const float *img = (const float *)smem;
@@ -853,14 +914,38 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         r_begin = __builtin_amdgcn_s_memrealtime();
     }
 
-    // Workgroup w owns batches w, w + gridDim, w + 2 gridDim, ...; its waves claim them from a queue
-    // in LDS (the older wave of a SIMD wins the arbitration for the matrix pipe, so a fixed split
-    // would leave the younger one alone with a quarter of its batches after its partner has exited).
-    auto claim = [&]() -> uint64_t {
-        uint32_t q = 0u;
-        if (lane == 0) q = __hip_atomic_fetch_add(&queue_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-        return (uint64_t)blockIdx.x + (uint64_t)gridDim.x * q;
+    // Batches are claimed, BLOCK at a time, by each wave from one global counter (zeroed before the
+    // launch).  Static ownership fails twice here: the older wave of a SIMD wins the arbitration for the
+    // matrix pipe, so equal shares leave the younger one alone with a quarter of its batches after its
+    // partner has exited; and when another kernel (the RCCL gather of the previous chunk) holds some CUs
+    // at launch, the workgroups that start late would still own a full share.  The returning atomic for
+    // the next block is issued two batches before its value is needed.
+    constexpr uint32_t BLOCK = 4;
+    uint32_t pending = 0u;                             // lane 0: first batch of the next block (in flight)
+    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;     // every wave's first block is fixed
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    auto request = [&]() {
+        uint32_t fresh;                                // deliberately undefined off lane 0: no merge copy, so the
+        if (lane == 0)                                 // compiler's wait for the atomic lands at the first use
+            fresh = first_dynamic + __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    };
+#pragma clang diagnostic pop
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    uint32_t in_block = 0;                             // position of b inside the current block
+    request();
+    // the batch after (block0, in_block)
+    auto successor = [&](uint64_t &nb0, uint32_t &nin) {
+        if (in_block + 1 < BLOCK) {
+            nb0 = block0;
+            nin = in_block + 1;
+        } else {
+            uint32_t p = pending;
+            asm volatile("" : "+v"(p));                // keeps the broadcast (and the wait for the atomic) here
+            nb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+            nin = 0;
+        }
     };
     // Rows come in through a buffer descriptor rebased per batch (wave-uniform, so the 4 GiB offset
     // range is per batch, not per matrix): rows past N read as zeros by the hardware range check, one
@@ -887,11 +972,14 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
         }
     };
-    uint64_t b = claim();
+    uint64_t b = block0;
     fetch(b);
 
     while (b < a.nbatches) {
-        const uint64_t bnext = claim();
+        uint64_t nb0;
+        uint32_t nin;
+        successor(nb0, nin);
+        const uint64_t bnext = nb0 + nin;
         f32x4 xf[R / 8];
         float ss = 0.0f;
 #pragma unroll
@@ -905,6 +993,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge rows: exact scan at the end
         const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
         lap(0);                                        // 0: delivery of this batch's rows
+        // vmcnt counts in issue order: the atomic goes out only after this batch's rows have been waited
+        // for, or that wait would include the atomic's own round trip
+        asm volatile("" ::: "memory");
+        if (nin == 0) request();                       // the block after the one just taken
         fetch(bnext);
         lap(1);                                        // 1: issue of the next batch's loads
 
@@ -953,6 +1045,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         }
         lap(3);                                        // 3: batch epilogue
         b = bnext;
+        block0 = nb0;
+        in_block = nin;
     }
     if (DIAG && a.dbg && lane == 0) {
         unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
@@ -971,7 +1065,7 @@ struct EngineModel {
     uint32_t K = 0, D = 0, M = 0, R1 = 0, R2 = 0, tiles_per_proto = 0;
     bool has_cls = false;
     float *img1 = nullptr, *img2 = nullptr, *plain = nullptr;
-    uint32_t *cls = nullptr;
+    uint32_t *cls = nullptr, *queue = nullptr;
     uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
     const char *name = "mfma";
     hipError_t (*launch)(const EngineModel &, const EngineArgs &, bool matched, hipStream_t) = nullptr;
@@ -1027,16 +1121,17 @@ hipError_t to_device(T **dst, const std::vector<T> &src)
 }
 
 // WPS = workgroups per CU = waves per SIMD the register budget is cut for (256-thread workgroups).
-template <int MODE, int R1, int R2, int S, int WPS, int ABL = 0>
+template <int MODE, int R1, int R2, int S, int WPS>
 hipError_t launch_t(const EngineModel &m, const EngineArgs &a, bool matched, hipStream_t st)
 {
-    uint64_t cap = 256ull * WPS;                                      // 256 CUs x workgroups per CU
-    if (const char *g = getenv("VQHIP_GRID")) cap = (uint64_t)atoll(g);  // experiments only
+    const uint64_t cap = 256ull * WPS;                                // 256 CUs x workgroups per CU
     const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
+    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
     if (matched)
-        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS, ABL>), dim3(grid), dim3(256), 0, st, a, m.cls);
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS>), dim3(grid), dim3(256), 0, st, a, m.cls);
     else
-        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false, WPS, ABL>), dim3(grid), dim3(256), 0, st, a, m.cls);
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false, WPS>), dim3(grid), dim3(256), 0, st, a, m.cls);
     return hipGetLastError();
 }
 
@@ -1047,23 +1142,25 @@ void bind(EngineModel &m)
     m.samples_per_batch = 4 * S * 32;
 }
 
-template <int R, int S, int ABL = 0>
+template <int R, int S>
 hipError_t launch_resident(const EngineModel &, const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;                        // one batch of S*32 samples per wave
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);          // one 512-thread workgroup per CU
     if (matched)
-        hipLaunchKernelGGL((k_resident<R, S, true, ABL>), dim3(grid), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((k_resident<R, S, true>), dim3(grid), dim3(512), 0, st, a);
     else
-        hipLaunchKernelGGL((k_resident<R, S, false, ABL>), dim3(grid), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((k_resident<R, S, false>), dim3(grid), dim3(512), 0, st, a);
     return hipGetLastError();
 }
 
 template <int R, bool DIAG = false>
-hipError_t launch_resident_pipe(const EngineModel &, const EngineArgs &a, bool matched, hipStream_t st)
+hipError_t launch_resident_pipe(const EngineModel &m, const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
     if (DIAG && getenv("VQHIP_NW4"))
         hipLaunchKernelGGL((k_resident_pipe<R, false, true, 4>), dim3(grid), dim3(256), 0, st, a);
     else if (DIAG)
@@ -1089,28 +1186,19 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     // an even number of tiles: the pipelined kernel ping-pongs two accumulators (pad rows score +INF)
     img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
                            m.ngroups1, ((size_t)m.K + 63) / 64 * 64);
-    bind<MODE_EUCLID, R1, R1, (R1 >= 256 ? 1 : 2)>(m);
-    if (R1 < 256 && (size_t)m.ngroups1 * Geom<R1>::STAGE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
-        constexpr int S = R1 >= 256 ? 1 : 2;
-        m.launch = &launch_resident<R1, S>;
-        m.samples_per_batch = S * 32;
-        m.name = "mfma_euclid_lds";
-        if (m.D == (uint32_t)R1 && !getenv("VQHIP_NO_PIPE")) {       // unpadded rows: the pipelined kernel
-            m.samples_per_batch = 32;
-            m.launch = variant_env() == 31 ? &launch_resident_pipe<R1, true> : &launch_resident_pipe<R1>;
-            m.name = "mfma_euclid_lds_pipe";
+    bind<MODE_EUCLID, R1, R1, (R1 >= 128 ? 1 : 2)>(m);
+    if constexpr (R1 < 256) {
+        if ((size_t)m.ngroups1 * Geom<R1>::STAGE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
+            constexpr int S = 2;
+            m.launch = &launch_resident<R1, S>;
+            m.samples_per_batch = S * 32;
+            m.name = "mfma_euclid_lds";
+            if (m.D == (uint32_t)R1 && !getenv("VQHIP_NO_PIPE")) {       // unpadded rows: the pipelined kernel
+                m.samples_per_batch = 32;
+                m.launch = variant_env() == 31 ? &launch_resident_pipe<R1, true> : &launch_resident_pipe<R1>;
+                m.name = "mfma_euclid_lds_pipe";
+            }
         }
-        return true;
-    }
-    if constexpr (R1 == 128) {
-        const int v = variant_env();
-        if (v == 1) bind<MODE_EUCLID, R1, R1, 1, 3>(m);
-        if (v == 2) bind<MODE_EUCLID, R1, R1, 1, 4>(m);
-        if (v == 3) bind<MODE_EUCLID, R1, R1, 1, 2>(m);
-        if (v == 11) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 1>;   // ablations: wrong results, timing only
-        if (v == 12) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 2>;
-        if (v == 13) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 3>;
-        if (v == 14) m.launch = &launch_t<MODE_EUCLID, R1, R1, 2, 2, 4>;   // phase stamps (diagnostic)
     }
     return true;
 }
@@ -1246,6 +1334,7 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
     if (herr == hipSuccess && !img2.empty()) herr = to_device(&out->img2, img2);
     if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
     if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
+    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, sizeof(uint32_t));
     if (herr != hipSuccess) {
         engine_free(out);
         return nullptr;
@@ -1260,6 +1349,7 @@ void engine_free(EngineModel *m)
     (void)hipFree(m->img2);
     (void)hipFree(m->plain);
     (void)hipFree(m->cls);
+    (void)hipFree(m->queue);
     delete m;
 }
 
@@ -1279,12 +1369,11 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.ss_limit = m->ss_limit;
     a.dbg = nullptr;
     static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
-    if (variant_env() == 14 || variant_env() == 31) {
+    if (variant_env() == 31) {
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
-    a.stagger = getenv("VQHIP_STAGGER") ? atoi(getenv("VQHIP_STAGGER")) : 0;
-    a.stagger_sleeps = getenv("VQHIP_SLEEPS") ? atoi(getenv("VQHIP_SLEEPS")) : 8;
+    a.queue = m->queue;
     hipError_t e = m->launch(*m, a, dy != nullptr, s);
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch
         (void)hipStreamSynchronize(s);
