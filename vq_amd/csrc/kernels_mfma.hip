@@ -47,6 +47,7 @@ struct EngineArgs {
     uint32_t tiles_per_proto; // LOCAL: 32-row tiles per Omega_j
     uint64_t nbatches;
     Outputs out;
+    float wmax2;              // largest ||w_k||^2 (screening error bound)
     float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
@@ -556,19 +557,22 @@ template <int R>
 __device__ __forceinline__ float exact_sq_lds(const f32x4 (&xf)[R / 8], const float *img, uint32_t k, int h)
 {
     using Gm = Geom<R>;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
     const uint32_t r = k & 31u;
     const float *rowp = img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::chunk_off((int)r, h);
-    float p = 0.0f;
+    // two partial sums, v_pk_fma_f32: 4 VALU per chunk instead of 8 (VALU time is matrix-pipe time here)
+    f32x2 p = {0.0f, 0.0f};
+    const f32x2 half = {0.5f, 0.5f};
 #pragma unroll
     for (int j = 0; j < R / 8; ++j) {
         const f32x4 v = *(const f32x4 *)(rowp + 8 * j);                          // v = -2 w
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = fmaf(0.5f, v[e], xf[j][e]);                          // x - w, exact scaling
-            p = fmaf(d, d, p);
-        }
+        const f32x2 d0 = __builtin_elementwise_fma(half, f32x2{v[0], v[1]}, f32x2{xf[j][0], xf[j][1]});   // x - w, exact scaling
+        const f32x2 d1 = __builtin_elementwise_fma(half, f32x2{v[2], v[3]}, f32x2{xf[j][2], xf[j][3]});
+        p = __builtin_elementwise_fma(d0, d0, p);
+        p = __builtin_elementwise_fma(d1, d1, p);
     }
-    return p + xor32(p);
+    const float t = p[0] + p[1];
+    return t + xor32(t);
 }
 
 template <int R, int S, bool MATCHED>
@@ -824,7 +828,7 @@ __device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tpr
 // (x - w)^2 form from the LDS image, roots, compares like helpers.rs:70.
 template <int R, bool MATCHED>
 __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h,
-                                            bool unsafe, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
+                                            bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
 {
     using Gm = Geom<R>;
     if (!MATCHED) {
@@ -842,9 +846,16 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         if (f < KEY_VALID_BELOW && !unsafe) {
             const float d1 = sqrtf(exact_sq_lds<R>(xf, img, fi, h));
             wp.d = d1; wp.i = fi;
-            if (sd < KEY_VALID_BELOW) {
-                const float d2 = sqrtf(exact_sq_lds<R>(xf, img, si, h));
-                if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+            // The runner-up is re-measured only where it can still win: a key differs from the true
+            // ||x-w||^2 + (c - ||x||^2) by less than margin/2 (f32 accumulation of 2 x.w, rounding of the
+            // init column, the 4 truncated bits), so a gap above `margin` decides the order already.
+            // Decided per wave: the re-measurement is 80 VALU + 16 LDS reads for every lane or for none.
+            const bool close = sd < KEY_VALID_BELOW && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
+            if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+                if (sd < KEY_VALID_BELOW) {
+                    const float d2 = sqrtf(exact_sq_lds<R>(xf, img, si, h));
+                    if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+                }
             }
             unsafe = !(wp.d < INFINITY);
         } else {
@@ -920,7 +931,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     // partner has exited; and when another kernel (the RCCL gather of the previous chunk) holds some CUs
     // at launch, the workgroups that start late would still own a full share.  The returning atomic for
     // the next block is issued two batches before its value is needed.
-    constexpr uint32_t BLOCK = 4;
+    constexpr uint32_t BLOCK = 2;
     uint32_t pending = 0u;                             // lane 0: first batch of the next block (in flight)
     const uint32_t first_dynamic = gridDim.x * NW * BLOCK;     // every wave's first block is fixed
 #pragma clang diagnostic push
@@ -981,14 +992,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         successor(nb0, nin);
         const uint64_t bnext = nb0 + nin;
         f32x4 xf[R / 8];
-        float ss = 0.0f;
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        f32x2 ss2 = {0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < R / 8; ++j) {
             xf[j] = xn[j];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ss = fmaf(xf[j][e], xf[j][e], ss);
+            const f32x2 lo = {xf[j][0], xf[j][1]}, hi = {xf[j][2], xf[j][3]};
+            ss2 = __builtin_elementwise_fma(lo, lo, ss2);
+            ss2 = __builtin_elementwise_fma(hi, hi, ss2);
         }
         const uint32_t label = ln;
+        float ss = ss2[0] + ss2[1];
         ss += xor32(ss);                               // ||x||^2, the same value in both lanes of the pair
         const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge rows: exact scan at the end
         const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
@@ -1028,7 +1042,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         lap(2);                                        // 2: tile loop
 
         Best1 wp, wn;
-        finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, ku, km, wp, wn);
+        finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
         {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
             const int rec = (int)records(b, 4u);
             const uint32_t so = (uint32_t)s_col * 4u;
@@ -1070,7 +1084,7 @@ struct EngineModel {
     const char *name = "mfma";
     hipError_t (*launch)(const EngineModel &, const EngineArgs &, bool matched, hipStream_t) = nullptr;
     int samples_per_batch = 0;
-    float ss_limit = 0.0f;
+    float ss_limit = 0.0f, wmax2 = 0.0f;
 };
 
 namespace {
@@ -1290,6 +1304,7 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
         }
         // ||x||^2 below this: |2 x.w| <= 2 sqrt(ss wmax2) <= 1e18 and ||w||^2 + c stay far inside f32 range
         m.ss_limit = (float)std::min(1e36, 1e36 / (4.0 * std::max(wmax2, 1e-36)));
+        m.wmax2 = (float)wmax2;
         if (omega_kind == OMEGA_NONE) {
             m.mode = MODE_EUCLID;
             m.name = "mfma_euclid";
@@ -1367,6 +1382,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.nbatches = (N + m->samples_per_batch - 1) / m->samples_per_batch;
     a.out = out;
     a.ss_limit = m->ss_limit;
+    a.wmax2 = m->wmax2;
     a.dbg = nullptr;
     static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
     if (variant_env() == 31) {
