@@ -8,8 +8,10 @@
 A step = one pass of the hot path over this rank's resident synthetic shard (inputs already in
 HBM): N=1 runs BASELINE.json configs[1], "GLVQ predict, synthetic 10M x 128 fp32, 256 prototypes".
 With N ranks every rank holds its own 10M x 128 shard (weak scaling), prototypes replicated, and
-the only exchange is the RCCL all-gather of winner indices + distances, issued per chunk on a side
-stream so it overlaps the next chunk's kernel.
+the only exchange is the RCCL all-gather of winner indices + distances.  It runs on a side stream
+out of one of two alternating result buffers, so the gather of pass k overlaps the kernel of pass
+k+1 (the kernel claims its batches from a queue, so CUs the gather occupies at launch cost only
+their share of the work).  All gathers have completed before the timed region ends.
 
 One JSON line on rank 0: the contract fields plus
   roofline     dominant kernel (k_resident_pipe for c2; k_engine otherwise) against the f32 MFMA peak: algorithmic flops per launch
@@ -51,9 +53,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", help="config name in vq_amd.synth.CONFIGS")
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's N, capped at 10M)")
-    ap.add_argument("--gather-chunks", type=int, default=4, help="chunks per step when N > 1 (gather overlap)")
+    ap.add_argument("--gather-chunks", type=int, default=1, help="chunks per step when N > 1 (finer gather overlap)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the gather path (side stream, events, RCCL all_gather) even with one rank: rehearsal on a 1-GPU box")
     ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: libraries that write banners to fd 1 (RCCL prints its version
+    # there at communicator set-up) are pointed at stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -69,8 +79,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    gather = world > 1 or args.force_gather
+    if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     cfg = synth.CONFIGS[args.workload]
@@ -85,21 +97,29 @@ def main():
     # Block-cyclic sharding: chunk c of rank r = global rows [(c*world + r)*m, +m), so the all-gather of
     # chunk c lands as the contiguous global range [c*world*m, (c+1)*world*m): natural order, no copies.
     X = [synth.samples_device(ctx, model, sh.first_row(c), m_rows) for c in range(chunks)]
-    idx_loc = [torch.empty(m_rows, dtype=torch.int32, device=dev) for _ in range(chunks)]
-    dst_loc = [torch.empty(m_rows, dtype=torch.float32, device=dev) for _ in range(chunks)]
-    if world > 1:
+    # two result buffers per chunk, alternating by pass: the gather of pass k reads one while pass k+1 writes the other
+    idx_buf = [[torch.empty(m_rows, dtype=torch.int32, device=dev) for _ in range(chunks)] for _ in range(2)]
+    dst_buf = [[torch.empty(m_rows, dtype=torch.float32, device=dev) for _ in range(chunks)] for _ in range(2)]
+    idx_loc, dst_loc = idx_buf[0], dst_buf[0]
+    if gather:
         idx_all = torch.empty(sh.total_rows, dtype=torch.int32, device=dev)
         dst_all = torch.empty(sh.total_rows, dtype=torch.float32, device=dev)
         comm = torch.cuda.Stream(device=dev)
         computed = [torch.cuda.Event() for _ in range(chunks)]
-        gathered = [torch.cuda.Event() for _ in range(chunks)]
+        gathered = [[torch.cuda.Event() for _ in range(chunks)] for _ in range(2)]
     compute = torch.cuda.current_stream(dev)
     kernel_ms = []                                   # (start, end) event pairs around every launch
 
+    passes = [0]
+
     def step(timed):
+        nonlocal idx_loc, dst_loc
+        par = passes[0] & 1
+        passes[0] += 1
+        idx_loc, dst_loc = idx_buf[par], dst_buf[par]
         for c in range(chunks):
-            if world > 1:
-                compute.wait_event(gathered[c])      # previous step's gather has read idx_loc[c]
+            if gather:
+                compute.wait_event(gathered[par][c])     # the gather two passes ago has read this buffer
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(compute)
@@ -107,21 +127,22 @@ def main():
             if timed:
                 e1.record(compute)
                 kernel_ms.append((e0, e1))
-            if world > 1:
+            if gather:
                 computed[c].record(compute)
                 with torch.cuda.stream(comm):
                     comm.wait_event(computed[c])
                     gather_chunk(sh, c, idx_all, dst_all, idx_loc[c], dst_loc[c])
-                    gathered[c].record(comm)
+                    gathered[par][c].record(comm)
 
     def fence():
-        if world > 1:
+        if gather:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world > 1:
-        for e in gathered:
-            e.record(comm)
+    if gather:
+        for par in range(2):
+            for e in gathered[par]:
+                e.record(comm)
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -141,7 +162,7 @@ def main():
             g0 = sh.first_row(c)
             want = (torch.arange(g0, g0 + m_rows, device=dev) % cfg.K).to(torch.int32)
             assert bool((idx_loc[c] == want).all()), "assignment of the timed pass is wrong"
-        if world > 1:
+        if gather:
             want = (torch.arange(sh.total_rows, device=dev) % cfg.K).to(torch.int32)
             assert bool((idx_all == want).all()), "gathered assignment is wrong"
 
@@ -174,7 +195,7 @@ def main():
                                    + (f", Omega {cfg.M}x{cfg.D} ({cfg.omega})" if cfg.omega != "none" else ""),
                        "name": cfg.name, "rows_per_gpu": rows, "dim": cfg.D, "prototypes": cfg.K,
                        "gather_chunks": chunks, "kernel": ctx.last_kernel,
-                       "exchange": "rccl all_gather(idx u32, dist f32)" if world > 1 else "none"},
+                       "exchange": "rccl all_gather(idx u32, dist f32)" if gather else "none"},
             "roofline": {"bound": "mfma", "kernel": KERNEL_FN.get(ctx.last_kernel, "k_engine"), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                          "launch_ms": launch_ms, "flops_per_sample": fl, "samples_per_launch": m_rows,
@@ -200,8 +221,9 @@ def main():
                                     "sample": f"first {cpu_rows} rows of the same shard, f64 oracle, faithful mode "
                                               f"(Lambda rebuilt per pair where Omega is used), {cpu_s:.1f} s",
                                     "indices_equal_gpu": same}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if gather:
         dist.destroy_process_group()
     ctx.close()
 

@@ -422,3 +422,24 @@ def test_project_local(ctx, shape):
     with pytest.raises(VqhipError) as e:
         ctx.project(X, PROJECT_LAMBDA)
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("N", [1, 31, 32, 33, 63, 65, 4097])
+def test_pipelined_kernel_row_counts(ctx, N):
+    """Batches of 32 rows claimed in blocks of 2: rows past N are dropped by the buffer range check."""
+    rng = np.random.default_rng(N)
+    D, K = 128, 256
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 3, D)).astype(np.float32)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    import torch
+    Xd = torch.from_numpy(X).cuda()
+    idx = torch.full((N + 3,), -7, dtype=torch.int32, device="cuda")
+    dist = torch.full((N + 3,), -7.0, dtype=torch.float32, device="cuda")
+    ctx.assign_into(Xd[:N], idx[:N], dist[:N])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "mfma_euclid_lds_pipe"
+    assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()   # nothing written past N
+    rep = parity.compare(idx[:N].cpu().numpy(), dist[:N].cpu().numpy(), *oracle.assign(X[:N], W, threads=8))
+    assert rep.ok, str(rep)
