@@ -16,10 +16,10 @@ all: $(LIB) oracle $(MODELS_TEST)
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vq_common.h include/vqhip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/vq_common.h $(CSRC)/engine.h include/vqhip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/vq_common.h include/vqhip.h
+$(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/vq_common.h $(CSRC)/engine.h include/vqhip.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 # the C++ host mirror (include/vq_models.hpp) with its tests; plain g++ against the C ABI

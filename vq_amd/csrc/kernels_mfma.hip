@@ -283,23 +283,46 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
             stage_group<G1::STAGE_BYTES>(dst, (const char *)(a.img1 + (size_t)q * G1::STAGE_FLOATS), wave, lane);
     };
 
-    // this wave's S tiles of 32 samples of batch bb -> B fragments (straight from HBM, 16 B per lane)
+    // This wave's S tiles of 32 samples of batch bb -> B fragments, straight from HBM, 16 B per lane, through a
+    // buffer descriptor rebased per tile (wave-uniform): rows past N read as zeros by the hardware range
+    // check, one per-lane offset + immediates serves every chunk.  The loads are raw: nothing here waits for
+    // them, so a batch can be fetched while the previous one is searched.
     f32x4 xf[S][R1 / 8];
     uint32_t label[S];
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
     auto load_samples = [&](uint64_t bb) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const uint64_t smp = ((bb * 4 + wave) * S + s) * 32 + s_col;
-            const bool live = bb < a.nbatches && smp < a.N;
-            const float *xrow = a.X + smp * a.D;
-#pragma unroll
-            for (int j = 0; j < R1 / 8; ++j) {
-                const uint32_t c = 2 * j + h;
-                const bool ok = live && c < Cact;                 // load unconditionally from a safe address
-                const f32x4 v = *(const f32x4 *)(ok ? xrow + 4 * c : a.X);
-                xf[s][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint64_t first = ((bb * 4 + wave_u) * S + s) * 32;
+            uint32_t rec = 0u, rec_y = 0u;
+            if (bb < a.nbatches && first < a.N) {
+                const uint64_t left = a.N - first;
+                rec = left * row_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * row_bytes);
+                rec_y = left * 4u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * 4u);
             }
-            label[s] = (MATCHED && live) ? a.y[smp] : 0u;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + first * a.D), 0, (int)rec, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < R1 / 8; ++j)
+                xf[s][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+            if (MATCHED) {
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + first), 0, (int)rec_y, 0x00020000);
+                label[s] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+            } else {
+                label[s] = 0u;
+            }
+        }
+    };
+    // D < R1: the chunks past the row's end hold the next row's values (or range-check zeros); the weight
+    // images are zero there, but 0 x INF is NaN, so they are cleared before the rows are used
+    auto mask_columns = [&]() {
+        if (Cact < (uint32_t)(R1 / 4)) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int j = 0; j < R1 / 8; ++j)
+                    if ((uint32_t)(2 * j + h) >= Cact) xf[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -311,10 +334,18 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
         __syncthreads();                                             // waits vmcnt(0) for the DMA, then barrier
     }
 
+    // thread 0 keeps one claim in flight: the atomic issued at the top of batch k returns batch k + 2
+    uint32_t pending = 0u;
+    if (tid == 0) pending = gridDim.x + atomicAdd(a.queue, 1u);
+
     while (b < a.nbatches) {
-        if (tid == 0) claimed = gridDim.x + atomicAdd(a.queue, 1u);
+        if (tid == 0) {
+            claimed = pending;                                       // the wait for the atomic of a batch ago is here
+            pending = gridDim.x + atomicAdd(a.queue, 1u);
+        }
         __syncthreads();
         const uint64_t bnext = claimed;
+        mask_columns();
         uint64_t sample[S];
         uint32_t lab[S];
 #pragma unroll
@@ -352,8 +383,18 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
         auto step = [&](auto &&compute) {
             const bool wrap = q + 1 == ngroups;
             if (!(wrap && bnext >= a.nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);   // nothing to stage after the last batch
-            compute((const float *)(smem + cur * BUF_BYTES));
-            __syncthreads();                   // next stage landed (vmcnt(0)) and everyone is done reading this one
+            if (MODE == MODE_OMEGA && q == (uint32_t)NG1) {
+                // x is dead: the next batch's rows are fetched now and arrive while the search runs.  vmcnt
+                // counts in issue order, so they go out AFTER this step's DMA, and this step's barrier waits
+                // for everything but them (a barrier that waited for vmcnt(0) would sit out an HBM round trip).
+                load_samples(bnext);
+                compute((const float *)(smem + cur * BUF_BYTES));
+                static_assert(S * (R1 / 8) + 1 <= 63, "vmcnt is a 6-bit counter");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(S * (R1 / 8) + (MATCHED ? S : 0)) : "memory");
+            } else {
+                compute((const float *)(smem + cur * BUF_BYTES));
+                __syncthreads();               // next stage landed (vmcnt(0)) and everyone is done reading this one
+            }
             cur ^= 1;
             ++q;
         };
@@ -381,7 +422,6 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     });
                 });
             });
-            load_samples(bnext);               // x is dead: the next batch's rows arrive while the search runs
         }
 
         if constexpr (MODE != MODE_LOCAL) {
