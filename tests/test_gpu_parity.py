@@ -261,27 +261,40 @@ def test_host_path_multi_chunk(ctx):
 
 # ------------------------------------------------------------------ ties at scale (packed-key screening)
 
+@pytest.mark.parametrize("copies", [(64, 4), (50, 5)], ids=["4x64", "5x50"])
 @pytest.mark.parametrize("sign", ["positive_scores", "negative_scores"])
-def test_duplicate_prototypes_keep_the_lowest_index(ctx, sign):
-    """Every prototype appears 4 times (k, k+64, k+128, k+192): all four distances are bit-identical and
+def test_duplicate_prototypes_keep_the_lowest_index(ctx, sign, copies):
+    """Every prototype appears several times (k, k+B, k+2B, ...): all their distances are bit-identical and
     helpers.rs:70 keeps the first.  Exercises the tie rules of the pipelined kernel at every level
-    (inside a lane's tile, across tiles, across the lane pair); samples far from / close to the
-    origin make the raw screening scores ||w||^2 - 2 x.w positive / negative."""
+    (inside a lane's tile, across tiles, across the lane pair; B = 50 puts the copies at different
+    positions of their tiles, where the packed keys alone would not keep the first); samples far from /
+    close to the origin make the raw screening scores ||w||^2 - 2 x.w positive / negative.  The labelled
+    searches give the copies different classes, so the first ELIGIBLE copy must win (helpers.rs:113,122)."""
+    B, reps = copies
     rng = np.random.default_rng(7)
-    D, K, N = 128, 256, 4096
-    base = rng.uniform(-1, 1, size=(64, D)).astype(np.float32)
-    W = np.concatenate([base, base, base, base], axis=0)
-    X = (base[rng.integers(0, 64, size=N)] + 0.05 * rng.uniform(-1, 1, size=(N, D))).astype(np.float32)
+    D, N = 128, 4096
+    base = rng.uniform(-1, 1, size=(B, D)).astype(np.float32)
+    W = np.concatenate([base] * reps, axis=0)
+    K = W.shape[0]
+    X = (base[rng.integers(0, B, size=N)] + 0.05 * rng.uniform(-1, 1, size=(N, D))).astype(np.float32)
     if sign == "positive_scores":
         X *= np.float32(0.01)
     o = oracle.assign(X, W, threads=8)
-    assert (o[0] < 64).all()
+    assert (o[0] < B).all()
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
     for policy in POLICIES:
         ctx.set_kernel_policy(policy)
         ctx.set_prototypes(W)
         idx, dist = ctx.assign(X)
         rep = parity.compare(idx, dist, *o)
         assert rep.ok and rep.mismatches == 0, f"{ctx.last_kernel}: {rep}"
+        ctx.set_labels(cls)
+        jp, dp, jn, dn = ctx.assign_matched(X, y)
+        for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+            om = oracle.assign(X, W, proto_cls=cls, labels=y, matching=matching, threads=8)
+            rep = parity.compare(j, d, *om)
+            assert rep.ok and rep.mismatches == 0, f"{ctx.last_kernel} matching={matching}: {rep}"
 
 
 @pytest.mark.parametrize("K", [1, 2, 31, 33, 64, 65, 255, 256])
@@ -442,4 +455,77 @@ def test_pipelined_kernel_row_counts(ctx, N):
     assert ctx.last_kernel == "mfma_euclid_lds_pipe"
     assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()   # nothing written past N
     rep = parity.compare(idx[:N].cpu().numpy(), dist[:N].cpu().numpy(), *oracle.assign(X[:N], W, threads=8))
+    assert rep.ok, str(rep)
+
+
+# ------------------------------------------------------------------ resident low-rank Omega kernel (LiRaMLVQ shapes)
+
+LOWRANK = [(1, 256, 7, 16), (33, 256, 33, 16), (4097, 64, 1000, 16), (700, 128, 65, 5), (2000, 32, 12, 1)]
+
+
+@pytest.mark.parametrize("case", LOWRANK, ids=lambda c: "n%d_d%d_k%d_m%d" % c)
+def test_lowrank_resident_kernel(ctx, case):
+    """Omega with <= 16 rows, Omega and the projected prototypes resident in LDS (k_lowrank_pipe): unstructured
+    data, row counts around the 32-row batch, K around the tile boundaries, nothing written past N,
+    plain and matched searches (helpers.rs:35-45, 55-77, 91-132)."""
+    import torch
+    N, D, K, M = case
+    rng = np.random.default_rng(N + K)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 3, D)).astype(np.float32)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    ctx.set_omega(Om)
+    Xd = torch.from_numpy(X).cuda()
+    idx = torch.full((N + 3,), -7, dtype=torch.int32, device="cuda")
+    dist = torch.full((N + 3,), -7.0, dtype=torch.float32, device="cuda")
+    ctx.assign_into(Xd[:N], idx[:N], dist[:N])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "mfma_omega_lds"
+    assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()
+    rep = parity.compare(idx[:N].cpu().numpy(), dist[:N].cpu().numpy(), *oracle.assign(X[:N], W, omega=Om, threads=8), atol=2e-6)
+    print(case, rep)
+    assert rep.ok, str(rep)
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    ctx.set_labels(cls)
+    jp, dp, jn, dn = ctx.assign_matched(X[:N], y)
+    assert ctx.last_kernel == "mfma_omega_lds"
+    for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+        o = oracle.assign(X[:N], W, omega=Om, proto_cls=cls, labels=y, matching=matching, threads=8)
+        rep = parity.compare(j, d, *o, atol=2e-6)
+        assert rep.ok, f"{case} matching={matching}: {rep}"
+
+
+def test_lowrank_ties_nan_and_streamed_fallback(ctx):
+    rng = np.random.default_rng(5)
+    D, M, N = 128, 16, 1500
+    base = rng.uniform(-1, 1, size=(50, D)).astype(np.float32)
+    W = np.concatenate([base, base, base], axis=0)                    # every prototype three times: first one wins
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = (base[rng.integers(0, 50, size=N)] + 0.05 * rng.uniform(-1, 1, size=(N, D))).astype(np.float32)
+    X[7, 3] = np.nan
+    X[40, 100] = np.inf
+    X[1499, 0] = -np.inf
+    o = oracle.assign(X, W, omega=Om, threads=8)
+    assert (o[0] < 50).all() and o[0][7] == 0 and o[0][40] == 0 and o[0][1499] == 0
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    ctx.set_omega(Om)
+    idx, dist = ctx.assign(X)
+    assert ctx.last_kernel == "mfma_omega_lds"
+    rep = parity.compare(idx, dist, *o, atol=2e-6)
+    assert rep.ok and rep.mismatches == 0, str(rep)
+    assert np.isinf(dist[[7, 40, 1499]]).all()
+    # more projected prototypes than LDS holds: the streamed engine serves the same model family
+    K2, D2, N2 = 2000, 256, 150
+    W2 = rng.uniform(-1, 1, size=(K2, D2)).astype(np.float32)
+    Om2 = (rng.uniform(-1, 1, size=(M, D2)) / np.sqrt(M * D2 / 3.0)).astype(np.float32)
+    X2 = rng.uniform(-1, 1, size=(N2, D2)).astype(np.float32)
+    ctx.set_prototypes(W2)
+    ctx.set_omega(Om2)
+    idx, dist = ctx.assign(X2)
+    assert ctx.last_kernel == "mfma_omega"
+    rep = parity.compare(idx, dist, *oracle.assign(X2, W2, omega=Om2, threads=8), atol=2e-6)
     assert rep.ok, str(rep)

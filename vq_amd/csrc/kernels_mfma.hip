@@ -50,6 +50,10 @@ struct EngineArgs {
     float wmax2;              // largest ||w_k||^2 (screening error bound)
     float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
+    // Prototypes whose search-space rows are identical (null when the model has none): dup_first[k] = lowest
+    // index with k's row, dup_next[k] = next higher index with it.  See settle_ties.
+    const uint32_t *dup_first, *dup_next;
+    const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
 };
 
@@ -131,6 +135,24 @@ struct Best1 {
         if (lexless(o, oi, d, i)) { d = o; i = oi; }
     }
 };
+
+// Exact ties between identical prototypes.  The packed keys order equal scores by position inside the
+// tile before tile number, and keep only two (labelled searches: one) candidates, so among three
+// identical rows the one found need not be the first.  Identical rows have bit-identical distances, so
+// the winner is moved to the first ELIGIBLE prototype with its row (helpers.rs:70: strict '<' keeps the
+// first; helpers.rs:113 / :122: eligibility).  Costs one null test per batch for models without duplicates.
+template <bool MATCHED>
+__device__ __forceinline__ void settle_ties(const EngineArgs &a, uint32_t label, Best1 &wp, Best1 &wn)
+{
+    if (a.dup_first == nullptr) return;
+    auto lowest = [&](uint32_t k, bool want_match) {
+        uint32_t i = a.dup_first[k];
+        while (i != k && MATCHED && (a.cls[i] == label) != want_match) i = a.dup_next[i];
+        return i;
+    };
+    if (wp.d < INFINITY) wp.i = lowest(wp.i, true);
+    if (MATCHED && wn.d < INFINITY) wn.i = lowest(wn.i, false);
+}
 
 // ---- packed screening keys (what they are and why: the comment above k_resident_pipe)
 struct Keys2 {                       // unlabelled search: best two keys and their tiles
@@ -570,6 +592,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     }
                 }
                 if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, cls_plain, MATCHED, lab[s], wp, wn);
+                settle_ties<MATCHED>(a, lab[s], wp, wn);
             }
             if (live) {
                 if (h == 0) {
@@ -866,11 +889,16 @@ __device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tpr
 
 // Final step of a batch: the lane pair agrees on the candidates, re-measures them in the direct
 // (x - w)^2 form from the LDS image, roots, compares like helpers.rs:70.
-template <int R, bool MATCHED>
+template <int R, bool MATCHED, bool ROOT = true>
 __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h,
                                             bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
 {
     using Gm = Geom<R>;
+    // helpers.rs:23 (rooted) vs helpers.rs:44 (squared)
+    auto dist = [&](uint32_t k) {
+        const float d = exact_sq_lds<R>(xf, img, k, h);
+        return ROOT ? sqrtf(d) : d;
+    };
     if (!MATCHED) {
         // this lane's two candidates and the partner lane's, best two of the four by (key, index)
         const uint32_t k1 = key_row(ku.b1, ku.t1, h), k2 = key_row(ku.b2, ku.t2, h);
@@ -884,7 +912,7 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
             if (keyless(pb1, pk1, ku.b2, k2)) { sd = pb1; si = pk1; } else { sd = ku.b2; si = k2; }
         }
         if (f < KEY_VALID_BELOW && !unsafe) {
-            const float d1 = sqrtf(exact_sq_lds<R>(xf, img, fi, h));
+            const float d1 = dist(fi);
             wp.d = d1; wp.i = fi;
             // The runner-up is re-measured only where it can still win: a key differs from the true
             // ||x-w||^2 + (c - ||x||^2) by less than margin/2 (f32 accumulation of 2 x.w, rounding of the
@@ -893,7 +921,7 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
             const bool close = sd < KEY_VALID_BELOW && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
             if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
                 if (sd < KEY_VALID_BELOW) {
-                    const float d2 = sqrtf(exact_sq_lds<R>(xf, img, si, h));
+                    const float d2 = dist(si);
                     if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
                 }
             }
@@ -907,11 +935,11 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
         if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
         if (p < KEY_VALID_BELOW) {
-            wp.d = sqrtf(exact_sq_lds<R>(xf, img, kp, h)); wp.i = kp;
+            wp.d = dist(kp); wp.i = kp;
             unsafe |= !(wp.d < INFINITY);
         }
         if (n < KEY_VALID_BELOW) {
-            wn.d = sqrtf(exact_sq_lds<R>(xf, img, kn, h)); wn.i = kn;
+            wn.d = dist(kn); wn.i = kn;
             unsafe |= !(wn.d < INFINITY);
         }
     }
@@ -919,7 +947,7 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         wp = Best1();
         wn = Best1();
         for (uint32_t k = 0; k < K; ++k) {
-            const float d = sqrtf(exact_sq_lds<R>(xf, img, k, h));
+            const float d = dist(k);
             const uint32_t ck = MATCHED ? ((const uint32_t *)(img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::W_FLOATS))[32 + (k & 31)] : 0u;
             if (!MATCHED || ck == label) wp.offer(d, k);
             else wn.offer(d, k);
@@ -1083,6 +1111,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
 
         Best1 wp, wn;
         finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+        settle_ties<MATCHED>(a, label, wp, wn);
         {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
             const int rec = (int)records(b, 4u);
             const uint32_t so = (uint32_t)s_col * 4u;
@@ -1113,6 +1142,206 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     }
 }
 
+// ------------------------------------------------------------------------------ resident low-rank Omega kernel
+// LiRaMLVQ-shaped models (Omega with at most 16 rows, src/liramlvq/liramlvq.rs:287-307 through
+// helpers.rs:35-45): Omega AND the projected prototypes p_k = Omega w_k stay in LDS for the whole
+// launch (config 4: 16.3 + 88 KiB), so a wave never meets a barrier after the image load.
+//   * projection y = Omega x on v_mfma_f32_16x16x4_f32: 16 Omega rows on the M axis (a 32-row MFMA
+//     would spend half of its rows on padding), 2 groups of 16 samples on the N axis, the 4 lane
+//     groups share out the reduction index.  x is consumed straight out of the registers the loads
+//     of the previous batch filled, and the next batch's loads go out as soon as it is projected.
+//   * one lane <-> lane^16 exchange turns the 16x16 accumulators into the B fragment of the 32x32x2
+//     search stage; lane half h then holds y[8h .. 8h+7], so the prototype image is built with
+//     chunks 1 and 2 of every row swapped (image chunk 2j+h <- chunk 2h+j of p_k).
+//   * the search is k_resident_pipe's (half_step / packed keys / exact re-measurement) at R = 16,
+//     distance squared and not rooted (helpers.rs:44).
+template <int R1, bool MATCHED, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineArgs a)
+{
+    using Gs = Geom<16>;
+    constexpr int ROWF = R1 + 4;                       // Omega row stride in LDS: rows start 4 banks apart
+    constexpr int NJ = R1 / 16;                        // projection steps: 4 MFMAs per step and sample group
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const int n16 = lane & 15, kg = lane >> 4;
+    const uint32_t ntiles = a.ngroups2 * Gs::G;       // even (G = 8)
+    const uint32_t p_bytes = ntiles * Gs::TILE_BYTES;
+
+    {   // both images -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        auto to_lds = [&](uint32_t dst, const char *src, uint32_t bytes) {
+            for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+                const uint32_t off = p * 1024u + lane * 16u;
+                if (off < bytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                     (__attribute__((address_space(3))) void *)(smem + dst + p * 1024u), 16, 0, 0);
+            }
+        };
+        to_lds(0u, (const char *)a.img2, p_bytes);
+        to_lds(p_bytes, (const char *)a.img1, 16u * ROWF * 4u);
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+    const float *om = (const float *)(smem + p_bytes) + n16 * ROWF + kg * 4;   // this lane's Omega row and k group
+
+    // batch queue: as in k_resident_pipe
+    constexpr uint32_t BLOCK = 2;
+    uint32_t pending = 0u;
+    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    auto request = [&]() {
+        uint32_t fresh;
+        if (lane == 0)
+            fresh = first_dynamic + __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    };
+#pragma clang diagnostic pop
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    uint32_t in_block = 0;
+    request();
+    auto successor = [&](uint64_t &nb0, uint32_t &nin) {
+        if (in_block + 1 < BLOCK) {
+            nb0 = block0;
+            nin = in_block + 1;
+        } else {
+            uint32_t p = pending;
+            asm volatile("" : "+v"(p));
+            nb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+            nin = 0;
+        }
+    };
+    // lane (n16, kg) loads 16 B of row n16 (group 0) and row 16 + n16 (group 1) per step: chunk 4j + kg
+    constexpr uint32_t row_bytes = R1 * 4u;
+    const uint32_t voff0 = (uint32_t)n16 * row_bytes + (uint32_t)kg * 16u;
+    const uint32_t voff1 = voff0 + 16u * row_bytes;
+    f32x4 xn[2][NJ];
+    uint32_t ln = 0u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    auto fetch = [&](uint64_t bb) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R1), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            xn[0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff0 + j * 64, 0, 0));
+            xn[1][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff1 + j * 64, 0, 0));
+        }
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    uint64_t b = block0;
+    fetch(b);
+
+    while (b < a.nbatches) {
+        uint64_t nb0;
+        uint32_t nin;
+        successor(nb0, nin);
+        const uint64_t bnext = nb0 + nin;
+
+        // ---- projection: accA / accB = y of samples n16 / 16 + n16, rows 4 kg .. 4 kg + 3
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+        {
+            f32x4 anext = *(const f32x4 *)om;
+            static_for<0, NJ>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                const f32x4 acur = anext;
+                if constexpr (j + 1 < NJ) anext = *(const f32x4 *)(om + 16 * (j + 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[e], xn[0][j][e], accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[e], xn[1][j][e], accB, 0, 0, 0);
+                }
+            });
+        }
+        const uint32_t label = ln;
+        // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
+        // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
+        asm volatile("" ::: "memory");
+        if (nin == 0) request();
+        fetch(bnext);
+
+        // ---- 16x16 accumulators -> B fragment of the 32x32x2 search: lane (s, h) gets y[8h .. 8h+7] of sample s
+        f32x4 yf[2];
+        {
+            const bool up = (lane & 16) != 0;          // this lane's sample sits in group 1
+            f32x4 own, recv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                own[r] = up ? accB[r] : accA[r];
+                const float send = up ? accA[r] : accB[r];
+                recv[r] = __shfl_xor(send, 16, 64);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yf[0][r] = up ? recv[r] : own[r];
+                yf[1][r] = up ? own[r] : recv[r];
+            }
+        }
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
+        ss += xor32(ss);                               // ||y||^2, the same value in both lanes of the pair
+        const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge: exact scan at the end
+        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+
+        // ---- search in the projected space (k_resident_pipe's tile loop at R = 16)
+        Keys2 ku;
+        KeysM km;
+        f32x16 acc0, acc1;
+        f32x4 a0 = *(const f32x4 *)(img + Gs::chunk_off(s_col, h));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
+            acc0[4 * g + 0] = ci[0] + c; acc0[4 * g + 1] = ci[1] + c; acc0[4 * g + 2] = ci[2] + c; acc0[4 * g + 3] = ci[3] + c;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = INFINITY;
+        const float *tprev = img;
+        uint32_t tid = 0;
+        for (uint32_t t = 0; t < ntiles; t += 2) {
+            const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
+            const float *tile1 = tile + Gs::TILE_FLOATS;
+            const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
+            half_step<16, MATCHED>(tile, tile1, tprev, tid, label, c, yf, acc0, acc1, a0, s_col, h, ku, km);
+            half_step<16, MATCHED>(tile1, next, tile, t, label, c, yf, acc1, acc0, a0, s_col, h, ku, km);
+            tprev = tile1;
+            tid = t + 1;
+        }
+        last_screen<16, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+
+        Best1 wp, wn;
+        finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+        settle_ties<MATCHED>(a, label, wp, wn);
+        {
+            const int rec = (int)records(b, 4u);
+            const uint32_t so = (uint32_t)s_col * 4u;
+            auto put = [&](void *base, uint32_t bits) {
+                __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+            };
+            if (h == 0) {
+                if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+            } else {
+                if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+            }
+        }
+        b = bnext;
+        block0 = nb0;
+        in_block = nin;
+    }
+}
+
 // ------------------------------------------------------------------------------ host side
 struct EngineModel {
     int mode = MODE_EUCLID;
@@ -1120,6 +1349,7 @@ struct EngineModel {
     bool has_cls = false;
     float *img1 = nullptr, *img2 = nullptr, *plain = nullptr;
     uint32_t *cls = nullptr, *queue = nullptr;
+    uint32_t *dup_first = nullptr, *dup_next = nullptr;     // identical search-space rows (null: none)
     uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
     const char *name = "mfma";
     hipError_t (*launch)(const EngineModel &, const EngineArgs &, bool matched, hipStream_t) = nullptr;
@@ -1164,6 +1394,37 @@ std::vector<float> build_images(const float *rows, size_t nrows, size_t len, siz
         }
     }
     return img;
+}
+
+// Groups of prototypes with identical rows (-0 counted as +0): first / next tables for settle_ties, left
+// empty when every row is unique.
+void find_duplicates(const std::vector<float> &Q, uint32_t K, uint32_t L, std::vector<uint32_t> &first, std::vector<uint32_t> &next)
+{
+    std::vector<float> canon(Q.begin(), Q.begin() + (size_t)K * L);
+    for (float &v : canon) v += 0.0f;
+    auto row_cmp = [&](uint32_t x, uint32_t y) { return std::memcmp(&canon[(size_t)x * L], &canon[(size_t)y * L], L * sizeof(float)); };
+    std::vector<uint32_t> order(K);
+    for (uint32_t k = 0; k < K; ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const int c = row_cmp(x, y);
+        return c < 0 || (c == 0 && x < y);
+    });
+    bool any = false;
+    std::vector<uint32_t> f(K), n(K);
+    for (uint32_t i = 0; i < K;) {
+        uint32_t j = i + 1;
+        while (j < K && row_cmp(order[i], order[j]) == 0) ++j;
+        for (uint32_t t = i; t < j; ++t) {
+            f[order[t]] = order[i];
+            n[order[t]] = t + 1 < j ? order[t + 1] : order[t];
+        }
+        any |= j - i > 1;
+        i = j;
+    }
+    if (any) {
+        first = std::move(f);
+        next = std::move(n);
+    }
 }
 
 template <class T>
@@ -1226,6 +1487,20 @@ hipError_t launch_resident_pipe(const EngineModel &m, const EngineArgs &a, bool 
     return hipGetLastError();
 }
 
+template <int R1>
+hipError_t launch_lowrank(const EngineModel &m, const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_lowrank_pipe<R1, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_lowrank_pipe<R1, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
 int variant_env()
 {
     const char *v = getenv("VQHIP_VARIANT");     // experiments only: picks among co-compiled tilings
@@ -1266,6 +1541,39 @@ bool bind_omega(EngineModel &m, std::vector<float> &img1, std::vector<float> &im
     img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
                             m.ngroups2);
     bind<MODE_OMEGA, R1, R2, 1>(m);
+    return true;
+}
+
+// Omega with at most 16 rows, unpadded sample rows, both images resident in LDS: k_lowrank_pipe
+template <int R1>
+bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
+                  const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
+{
+    if (m.D != (uint32_t)R1 || m.M > 16 || getenv("VQHIP_NO_RESIDENT")) return false;
+    constexpr int ROWF = R1 + 4;
+    // p_k with chunks 1 and 2 swapped (see the kernel), zero padded to 16
+    std::vector<float> Pp((size_t)m.K * 16, 0.0f);
+    static const int actual_chunk[4] = {0, 2, 1, 3};
+    for (uint32_t k = 0; k < m.K; ++k)
+        for (int ci = 0; ci < 4; ++ci)
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t d = 4u * actual_chunk[ci] + e;
+                if (d < m.M) Pp[(size_t)k * 16 + 4 * ci + e] = P[(size_t)k * m.M + d];
+            }
+    uint32_t ngroups2 = 0;
+    std::vector<float> pimg = build_images<16>(Pp.data(), m.K, 16, 16, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
+                                               INFINITY, ngroups2);
+    if (pimg.size() * sizeof(float) + (size_t)16 * ROWF * sizeof(float) > (size_t)RES_BYTES) return false;
+    img2 = std::move(pimg);
+    m.ngroups2 = ngroups2;
+    img1.assign((size_t)16 * ROWF, 0.0f);                              // Omega rows, row stride R1 + 4
+    for (uint32_t r = 0; r < m.M; ++r) std::memcpy(&img1[(size_t)r * ROWF], &Om[(size_t)r * m.D], m.D * sizeof(float));
+    m.ngroups1 = 1;
+    m.R1 = R1;
+    m.R2 = 16;
+    m.launch = &launch_lowrank<R1>;
+    m.samples_per_batch = 32;
+    m.name = "mfma_omega_lds";
     return true;
 }
 
@@ -1313,6 +1621,7 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
     m.R1 = (uint32_t)pad_pow2(D, 16);
     m.has_cls = !cls.empty();
     std::vector<float> img1, img2, plain;
+    std::vector<uint32_t> dup_first, dup_next;
     bool ok = false;
 
     if (omega_kind == OMEGA_NONE || omega_kind == OMEGA_GLOBAL) {
@@ -1357,13 +1666,16 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
             m.name = "mfma_omega";
             m.R2 = (uint32_t)pad_pow2(M, 16);
             m.ldp = m.R2;
-            ok = bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
+            ok = bind_lowrank<256>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<128>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_lowrank<64>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<32>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega<16, 16>(m, img1, img2, Om, P, norms, cls) || bind_omega<32, 16>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega<32, 32>(m, img1, img2, Om, P, norms, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, norms, cls);
         }
         // zero-padded plain rows for the exact re-measurement
         plain.assign((size_t)K * m.ldp, 0.0f);
         for (uint32_t k = 0; k < K; ++k) std::memcpy(&plain[(size_t)k * m.ldp], &Q[(size_t)k * L], L * sizeof(float));
+        find_duplicates(Q, K, L, dup_first, dup_next);
     } else {
         m.mode = MODE_LOCAL;
         m.name = "mfma_local";
@@ -1389,6 +1701,8 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
     if (herr == hipSuccess && !img2.empty()) herr = to_device(&out->img2, img2);
     if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
     if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
+    if (herr == hipSuccess && !dup_first.empty()) herr = to_device(&out->dup_first, dup_first);
+    if (herr == hipSuccess && !dup_next.empty()) herr = to_device(&out->dup_next, dup_next);
     if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, sizeof(uint32_t));
     if (herr != hipSuccess) {
         engine_free(out);
@@ -1405,6 +1719,8 @@ void engine_free(EngineModel *m)
     (void)hipFree(m->plain);
     (void)hipFree(m->cls);
     (void)hipFree(m->queue);
+    (void)hipFree(m->dup_first);
+    (void)hipFree(m->dup_next);
     delete m;
 }
 
@@ -1430,6 +1746,9 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
         a.dbg = dbg_buf;
     }
     a.queue = m->queue;
+    a.dup_first = m->dup_first;
+    a.dup_next = m->dup_next;
+    a.cls = m->cls;
     hipError_t e = m->launch(*m, a, dy != nullptr, s);
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch
         (void)hipStreamSynchronize(s);
