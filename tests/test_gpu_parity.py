@@ -460,12 +460,14 @@ def test_pipelined_kernel_row_counts(ctx, N):
 
 # ------------------------------------------------------------------ resident low-rank Omega kernel (LiRaMLVQ shapes)
 
-LOWRANK = [(1, 256, 7, 16), (33, 256, 33, 16), (4097, 64, 1000, 16), (700, 128, 65, 5), (2000, 32, 12, 1)]
+LOWRANK = [(1, 256, 7, 16), (33, 256, 33, 16), (4097, 64, 1000, 16), (700, 128, 65, 5), (2000, 32, 12, 1),
+           # Omega about square: prototypes resident, Omega streamed from L2 (k_omega_pipe)
+           (4097, 128, 256, 128), (65, 128, 1, 100), (900, 64, 70, 50), (31, 32, 10, 20)]
 
 
 @pytest.mark.parametrize("case", LOWRANK, ids=lambda c: "n%d_d%d_k%d_m%d" % c)
 def test_lowrank_resident_kernel(ctx, case):
-    """Omega with <= 16 rows, Omega and the projected prototypes resident in LDS (k_lowrank_pipe): unstructured
+    """Omega models with the projected prototypes resident in LDS (k_lowrank_pipe, k_omega_pipe): unstructured
     data, row counts around the 32-row batch, K around the tile boundaries, nothing written past N,
     plain and matched searches (helpers.rs:35-45, 55-77, 91-132)."""
     import torch
@@ -482,7 +484,8 @@ def test_lowrank_resident_kernel(ctx, case):
     dist = torch.full((N + 3,), -7.0, dtype=torch.float32, device="cuda")
     ctx.assign_into(Xd[:N], idx[:N], dist[:N])
     torch.cuda.synchronize()
-    assert ctx.last_kernel == "mfma_omega_lds"
+    want_kernel = "mfma_omega_lowrank_lds" if M <= 16 else "mfma_omega_lds"
+    assert ctx.last_kernel == want_kernel
     assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()
     rep = parity.compare(idx[:N].cpu().numpy(), dist[:N].cpu().numpy(), *oracle.assign(X[:N], W, omega=Om, threads=8), atol=2e-6)
     print(case, rep)
@@ -491,7 +494,7 @@ def test_lowrank_resident_kernel(ctx, case):
     y = rng.integers(0, 3, size=N).astype(np.uint32)
     ctx.set_labels(cls)
     jp, dp, jn, dn = ctx.assign_matched(X[:N], y)
-    assert ctx.last_kernel == "mfma_omega_lds"
+    assert ctx.last_kernel == want_kernel
     for matching, j, d in ((True, jp, dp), (False, jn, dn)):
         o = oracle.assign(X[:N], W, omega=Om, proto_cls=cls, labels=y, matching=matching, threads=8)
         rep = parity.compare(j, d, *o, atol=2e-6)
@@ -513,11 +516,15 @@ def test_lowrank_ties_nan_and_streamed_fallback(ctx):
     ctx.set_kernel_policy(KERNEL_AUTO)
     ctx.set_prototypes(W)
     ctx.set_omega(Om)
-    idx, dist = ctx.assign(X)
-    assert ctx.last_kernel == "mfma_omega_lds"
-    rep = parity.compare(idx, dist, *o, atol=2e-6)
-    assert rep.ok and rep.mismatches == 0, str(rep)
-    assert np.isinf(dist[[7, 40, 1499]]).all()
+    for Om_, want in ((Om, "mfma_omega_lowrank_lds"), (np.concatenate([Om] * 5, axis=0), "mfma_omega_lds")):
+        o = oracle.assign(X, W, omega=Om_, threads=8)
+        ctx.set_prototypes(W)
+        ctx.set_omega(Om_)
+        idx, dist = ctx.assign(X)
+        assert ctx.last_kernel == want
+        rep = parity.compare(idx, dist, *o, atol=2e-6)
+        assert rep.ok and rep.mismatches == 0, f"{want}: {rep}"
+        assert np.isinf(dist[[7, 40, 1499]]).all()
     # more projected prototypes than LDS holds: the streamed engine serves the same model family
     K2, D2, N2 = 2000, 256, 150
     W2 = rng.uniform(-1, 1, size=(K2, D2)).astype(np.float32)

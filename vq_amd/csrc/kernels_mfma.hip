@@ -1342,6 +1342,190 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
     }
 }
 
+// ------------------------------------------------------------------------------ resident-prototype Omega kernel
+// GMLVQ-shaped models (Omega with about as many rows as columns, src/gmlvq/gmlvq.rs:270-290 through
+// helpers.rs:35-45): the projected prototypes p_k = Omega w_k stay in LDS for the whole launch as in
+// k_resident_pipe (config 3: 134 KiB), which leaves no room for Omega (66 KiB).  Omega's A fragments
+// come straight from L2 instead: the host lays Omega out as one 1 KiB piece per (tile, reduction step)
+// -- 16 bytes per lane, exactly the fragment -- and every wave keeps a ring of DEPTH pieces in flight
+// ahead of its MFMAs.  No LDS stage, no barrier after the image load: waves run independently and
+// claim batches from the queue.  The projection's accumulators are the search stage's B fragment
+// (engine.h), the search is k_resident_pipe's, distance squared and not rooted (helpers.rs:44).
+template <int R, bool MATCHED, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs a)
+{
+    using Gs = Geom<R>;
+    constexpr int NT = R / 32, NJ = R / 8, NSTEP = NT * NJ;   // Omega tiles, reduction steps per tile, pieces
+    constexpr int DEPTH = 6;                                  // Omega pieces in flight per wave
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = a.ngroups2 * Gs::G;       // even (host pads)
+
+    {   // prototype image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        const uint32_t bytes = ntiles * Gs::TILE_BYTES;
+        const char *src = (const char *)a.img2;
+        for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+    // Omega pieces: piece i = (tile i / NJ, step i % NJ), this lane's 16 bytes at i * 1024 + lane * 16
+    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, NSTEP * 1024, 0x00020000);
+    const uint32_t om_off = (uint32_t)lane * 16u;
+    auto piece = [&](int i) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, i * 1024, 0));
+    };
+
+    // batch queue: as in k_resident_pipe
+    constexpr uint32_t BLOCK = 2;
+    uint32_t pending = 0u;
+    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    auto request = [&]() {
+        uint32_t fresh;
+        if (lane == 0)
+            fresh = first_dynamic + __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    };
+#pragma clang diagnostic pop
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    uint32_t in_block = 0;
+    request();
+    auto successor = [&](uint64_t &nb0, uint32_t &nin) {
+        if (in_block + 1 < BLOCK) {
+            nb0 = block0;
+            nin = in_block + 1;
+        } else {
+            uint32_t p = pending;
+            asm volatile("" : "+v"(p));
+            nb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+            nin = 0;
+        }
+    };
+    const uint32_t row_bytes = R * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    f32x4 xn[R / 8];                                   // rows of the next batch, in flight
+    uint32_t ln = 0u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    auto fetch = [&](uint64_t bb) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j)
+            xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    uint64_t b = block0;
+    fetch(b);
+
+    while (b < a.nbatches) {
+        uint64_t nb0;
+        uint32_t nin;
+        successor(nb0, nin);
+        const uint64_t bnext = nb0 + nin;
+
+        // ---- projection y = Omega x: 32 Omega rows per tile, A fragments from the ring; the accumulators of
+        //      tile t are chunks 2(4t + g) + h of y, i.e. fragment entries 4t + g of the search stage
+        f32x4 yf[R / 8];
+        {
+            f32x4 ring[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = piece(i);
+            static_for<0, NT>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                static_for<0, NJ>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value, i = t * NJ + j;
+                    const f32x4 av = ring[i % DEPTH];
+                    if constexpr (i + DEPTH < NSTEP) ring[i % DEPTH] = piece(i + DEPTH);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xn[j][e], acc, 0, 0, 0);
+                });
+#pragma unroll
+                for (int g = 0; g < 4; ++g) yf[4 * t + g] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            });
+        }
+        const uint32_t label = ln;
+        // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
+        // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
+        asm volatile("" ::: "memory");
+        if (nin == 0) request();
+        fetch(bnext);
+
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
+        ss += xor32(ss);                               // ||y||^2, the same value in both lanes of the pair
+        const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge: exact scan at the end
+        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+
+        // ---- search in the projected space (k_resident_pipe's tile loop)
+        Keys2 ku;
+        KeysM km;
+        f32x16 acc0, acc1;
+        f32x4 a0 = *(const f32x4 *)(img + Gs::chunk_off(s_col, h));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
+            acc0[4 * g + 0] = ci[0] + c; acc0[4 * g + 1] = ci[1] + c; acc0[4 * g + 2] = ci[2] + c; acc0[4 * g + 3] = ci[3] + c;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = INFINITY;
+        const float *tprev = img;
+        uint32_t tid = 0;
+        for (uint32_t t = 0; t < ntiles; t += 2) {
+            const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
+            const float *tile1 = tile + Gs::TILE_FLOATS;
+            const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
+            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, c, yf, acc0, acc1, a0, s_col, h, ku, km);
+            half_step<R, MATCHED>(tile1, next, tile, t, label, c, yf, acc1, acc0, a0, s_col, h, ku, km);
+            tprev = tile1;
+            tid = t + 1;
+        }
+        last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+
+        Best1 wp, wn;
+        finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+        settle_ties<MATCHED>(a, label, wp, wn);
+        {
+            const int rec = (int)records(b, 4u);
+            const uint32_t so = (uint32_t)s_col * 4u;
+            auto put = [&](void *base, uint32_t bits) {
+                __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+            };
+            if (h == 0) {
+                if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+            } else {
+                if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+            }
+        }
+        b = bnext;
+        block0 = nb0;
+        in_block = nin;
+    }
+}
+
 // ------------------------------------------------------------------------------ host side
 struct EngineModel {
     int mode = MODE_EUCLID;
@@ -1501,6 +1685,20 @@ hipError_t launch_lowrank(const EngineModel &m, const EngineArgs &a, bool matche
     return hipGetLastError();
 }
 
+template <int R>
+hipError_t launch_omega_pipe(const EngineModel &m, const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_omega_pipe<R, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_omega_pipe<R, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
 int variant_env()
 {
     const char *v = getenv("VQHIP_VARIANT");     // experiments only: picks among co-compiled tilings
@@ -1572,6 +1770,34 @@ bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &
     m.R1 = R1;
     m.R2 = 16;
     m.launch = &launch_lowrank<R1>;
+    m.samples_per_batch = 32;
+    m.name = "mfma_omega_lowrank_lds";
+    return true;
+}
+
+// Omega padded to R x R with D == R, projected prototypes resident in LDS, Omega from L2: k_omega_pipe
+template <int R>
+bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
+                     const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
+{
+    if (m.D != (uint32_t)R || m.R2 != (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;
+    uint32_t ngroups2 = 0;
+    std::vector<float> pimg = build_images<R>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
+                                              INFINITY, ngroups2, ((size_t)m.K + 63) / 64 * 64);
+    if (pimg.size() * sizeof(float) > (size_t)RES_BYTES) return false;
+    img2 = std::move(pimg);
+    m.ngroups2 = ngroups2;
+    // Omega as A-fragment pieces: piece (t, j), lane (row, h) = Omega[32 t + row][4 (2 j + h) .. + 3]
+    constexpr int NT = R / 32, NJ = R / 8;
+    img1.assign((size_t)NT * NJ * 64 * 4, 0.0f);
+    for (int t = 0; t < NT; ++t)
+        for (int j = 0; j < NJ; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const uint32_t row = 32u * t + (lane & 31), col = 4u * (2 * j + (lane >> 5));
+                if (row < m.M) std::memcpy(&img1[(((size_t)t * NJ + j) * 64 + lane) * 4], &Om[(size_t)row * m.D + col], 4 * sizeof(float));
+            }
+    m.ngroups1 = 1;
+    m.launch = &launch_omega_pipe<R>;
     m.samples_per_batch = 32;
     m.name = "mfma_omega_lds";
     return true;
@@ -1668,6 +1894,8 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
             m.ldp = m.R2;
             ok = bind_lowrank<256>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<128>(m, img1, img2, Om, P, norms, cls) ||
                  bind_lowrank<64>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<32>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega_pipe<128>(m, img1, img2, Om, P, norms, cls) || bind_omega_pipe<64>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega_pipe<32>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega<16, 16>(m, img1, img2, Om, P, norms, cls) || bind_omega<32, 16>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega<32, 32>(m, img1, img2, Om, P, norms, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, norms, cls);
