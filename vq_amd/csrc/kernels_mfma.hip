@@ -155,13 +155,22 @@ __device__ __forceinline__ void settle_ties(const EngineArgs &a, uint32_t label,
 }
 
 // ---- packed screening keys (what they are and why: the comment above k_resident_pipe)
+// Keys are f32 bit patterns and are compared AS FLOATS (v_min_f32 / v_med3_f32), so a score may have
+// either sign and the accumulators start at the plain ||w_k||^2 column.  Nothing that is screened may be
+// a NaN pattern (v_med3_f32 returns the minimum when it sees one): pad rows and the "tile before the
+// first" score PAD_SCORE, finite and above every real score (< 1e38 by ss_limit), instead of +INF,
+// whose pattern with position bits set is a NaN.  NaN / INF scores come only from samples that are
+// sent to the exact scan anyway.
+constexpr uint32_t KEY_NONE = 0x7F800000u;           // +INF: "no candidate yet"
+constexpr float PAD_SCORE = 3.0e38f;
+constexpr float KEY_VALID_F = 1.0e38f;               // keys of real prototypes are below this
 struct Keys2 {                       // unlabelled search: best two keys and their tiles
-    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu, t1 = 0u, t2 = 0u;
+    uint32_t b1 = KEY_NONE, b2 = KEY_NONE, t1 = 0u, t2 = 0u;
 };
 struct KeysM {                       // labelled search: best key with cls == y, best with cls != y
-    uint32_t p = 0xFFFFFFFFu, n = 0xFFFFFFFFu, tp = 0u, tn = 0u;
+    uint32_t p = KEY_NONE, n = KEY_NONE, tp = 0u, tn = 0u;
 };
-constexpr uint32_t KEY_VALID_BELOW = 0x7F800000u;   // keys of finite non-negative scores
+__device__ __forceinline__ bool key_valid(uint32_t key) { return __builtin_bit_cast(float, key) < KEY_VALID_F; }
 
 __device__ __forceinline__ uint32_t pack_key(float score, uint32_t o)
 {
@@ -169,12 +178,82 @@ __device__ __forceinline__ uint32_t pack_key(float score, uint32_t o)
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(score), "s"(0xFFFFFFF0u), "n"(o));
     return key;
 }
-__device__ __forceinline__ uint32_t umed3(uint32_t x, uint32_t y, uint32_t z)
+__device__ __forceinline__ uint32_t kmin(uint32_t x, uint32_t y)                     // minimum as floats
 {
     uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
+// The 16 scores of one finished tile offered to the lane's best two keys: position bits in, median, minimum
+// (3 VALU per score).  One asm statement: the compiler pads a wait state behind every inline-asm result
+// that the next instruction reads, and the chain b1 -> b1 would collect one per score.  PRE_NOPS: wait
+// states for accumulators that the MFMA right in front of the statement has written.
+template <int PRE_NOPS = 0>
+__device__ __forceinline__ void screen16(const f32x16 &sc, Keys2 &ku)
+{
+    uint32_t t0, t1;
+    if constexpr (PRE_NOPS > 0) asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
+    asm(
+        "v_and_or_b32 %[t0], %[s0], %[m], 0\n\t"
+        "v_and_or_b32 %[t1], %[s1], %[m], 1\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s2], %[m], 2\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s3], %[m], 3\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s4], %[m], 4\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s5], %[m], 5\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s6], %[m], 6\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s7], %[m], 7\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s8], %[m], 8\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s9], %[m], 9\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s10], %[m], 10\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s11], %[m], 11\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s12], %[m], 12\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s13], %[m], 13\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s14], %[m], 14\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s15], %[m], 15\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [s0] "v"(sc[0]), [s1] "v"(sc[1]), [s2] "v"(sc[2]), [s3] "v"(sc[3]), [s4] "v"(sc[4]), [s5] "v"(sc[5]), [s6] "v"(sc[6]), [s7] "v"(sc[7]), [s8] "v"(sc[8]), [s9] "v"(sc[9]), [s10] "v"(sc[10]), [s11] "v"(sc[11]), [s12] "v"(sc[12]), [s13] "v"(sc[13]), [s14] "v"(sc[14]), [s15] "v"(sc[15]), [m] "s"(0xFFFFFFF0u));
+}
+// After a tile's scores went in: which tile do the best two keys come from now
+__device__ __forceinline__ void settle_tiles(Keys2 &ku, const Keys2 &before, uint32_t tile_id)
+{
+    const bool c1 = ku.b1 != before.b1, c2 = ku.b2 != before.b2;
+    const uint32_t demoted = ku.b2 == before.b1 ? before.t1 : tile_id;
+    ku.t2 = c1 ? demoted : (c2 ? tile_id : before.t2);
+    ku.t1 = c1 ? tile_id : before.t1;
+}
+
 __device__ __forceinline__ uint32_t key_row(uint32_t key, uint32_t tile, int h)   // prototype index of a key
 {
     const uint32_t o = key & 15u;
@@ -183,7 +262,8 @@ __device__ __forceinline__ uint32_t key_row(uint32_t key, uint32_t tile, int h) 
 
 __device__ __forceinline__ bool keyless(uint32_t ak, uint32_t ai, uint32_t bk, uint32_t bi)
 {
-    return ak < bk || (ak == bk && ai < bi);
+    const float a = __builtin_bit_cast(float, ak), b = __builtin_bit_cast(float, bk);
+    return a < b || (a == b && ai < bi);
 }
 
 // LDS-DMA of one stage (BYTES, multiple of 16) from its pre-swizzled global image: a linear copy,
@@ -204,8 +284,7 @@ __device__ __forceinline__ void stage_group(char *lds_dst, const char *gsrc, int
 
 // acc[s] (+)= tile . xf[s]^T for one 32-row tile in LDS; accumulators start at the tile's init column.
 template <int R, int S>
-__device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S][R / 8], f32x16 (&acc)[S], const float (&shift)[S],
-                                         int row, int h)
+__device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S][R / 8], f32x16 (&acc)[S], int row, int h)
 {
     using Gm = Geom<R>;
     const float *tail = tile + Gm::W_FLOATS;
@@ -214,8 +293,8 @@ __device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S]
         const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            acc[s][4 * g + 0] = ci[0] + shift[s]; acc[s][4 * g + 1] = ci[1] + shift[s];
-            acc[s][4 * g + 2] = ci[2] + shift[s]; acc[s][4 * g + 3] = ci[3] + shift[s];
+            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
+            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
         }
     }
     const float *rowp = tile + Gm::chunk_off(row, h);
@@ -380,12 +459,11 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
         Keys2 ku[S];
         KeysM km[S];
         Best1 pos[S], neg[S];                                         // LOCAL: exact distances, offered in index order
-        float dsum[S], shift[S];
+        float dsum[S];
         bool unsafe[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             dsum[s] = 0.0f;
-            shift[s] = 0.0f;
             unsafe[s] = false;
         }
         if (MODE != MODE_OMEGA) {
@@ -429,10 +507,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     static_for<0, G1::G>([&](auto tt) {
                         constexpr int t = decltype(q1)::value * G1::G + decltype(tt)::value;
                         f32x16 acc[S];
-                        float zero[S];
-#pragma unroll
-                        for (int s = 0; s < S; ++s) zero[s] = 0.0f;
-                        tile_mma<R1, S>(stage + decltype(tt)::value * G1::TILE_FLOATS, xf, acc, zero, s_col, h);
+                        tile_mma<R1, S>(stage + decltype(tt)::value * G1::TILE_FLOATS, xf, acc, s_col, h);
                         static_for<0, 4>([&](auto g) {
                             constexpr int jj = 4 * t + decltype(g)::value;
                             if constexpr (jj < RS / 8) {
@@ -447,7 +522,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
         }
 
         if constexpr (MODE != MODE_LOCAL) {
-            // positivity shift of the screening scores: c = ||y||^2 (1 + 2^-8) + tiny (see k_resident_pipe)
+            // samples whose screening scores could leave the f32 range go to the exact scan
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 float ss = 0.0f;
@@ -457,7 +532,6 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     for (int e = 0; e < 4; ++e) ss = fmaf(yf[s][j][e], yf[s][j][e], ss);
                 ss += xor32(ss);
                 unsafe[s] = !(ss < a.ss_limit);
-                shift[s] = unsafe[s] ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
             }
         }
 
@@ -470,7 +544,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     for (int tt = 0; tt < G1::G; ++tt) {
                         const float *tile = stage + tt * G1::TILE_FLOATS;
                         f32x16 acc[S];
-                        tile_mma<R1, S>(tile, xf, acc, shift, s_col, h);
+                        tile_mma<R1, S>(tile, xf, acc, s_col, h);
                         const uint32_t ti = qs * G1::G + tt;
                         const uint32_t j = ti / a.tiles_per_proto, t = ti % a.tiles_per_proto;
 #pragma unroll
@@ -496,7 +570,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     for (int tt = 0; tt < G2::G; ++tt) {
                         const float *tile = stage + tt * G2::TILE_FLOATS;
                         f32x16 acc[S];
-                        tile_mma<RS, S>(tile, yf, acc, shift, s_col, h);
+                        tile_mma<RS, S>(tile, yf, acc, s_col, h);
                         const uint32_t tile_id = qs * G2::G + tt;
                         const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32 + 4 * h;
                         Keys2 ou[S];
@@ -506,32 +580,27 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                             ou[s] = ku[s];
                             om[s] = km[s];
                         }
-                        static_for<0, 16>([&](auto oo) {
-                            constexpr int o = decltype(oo)::value;
-                            uint32_t cls = 0u;
-                            if (MATCHED) cls = tcls[8 * (o >> 2) + (o & 3)];
+                        if constexpr (!MATCHED) {
 #pragma unroll
                             for (int s = 0; s < S; ++s) {
-                                const uint32_t key = pack_key(acc[s][o], o);
-                                if constexpr (!MATCHED) {
-                                    ku[s].b2 = umed3(ku[s].b1, ku[s].b2, key);
-                                    ku[s].b1 = ku[s].b1 < key ? ku[s].b1 : key;
-                                } else {
-                                    const bool match = cls == lab[s];                 // helpers.rs:113 / :122
-                                    const uint32_t kp = match ? key : 0xFFFFFFFFu, kn = match ? 0xFFFFFFFFu : key;
-                                    km[s].p = km[s].p < kp ? km[s].p : kp;
-                                    km[s].n = km[s].n < kn ? km[s].n : kn;
-                                }
+                                screen16<1>(acc[s], ku[s]);            // acc[s] is fresh from the matrix pipe
+                                settle_tiles(ku[s], ou[s], tile_id);
                             }
-                        });
+                        } else {
+                            static_for<0, 16>([&](auto oo) {
+                                constexpr int o = decltype(oo)::value;
+                                const uint32_t cls = tcls[8 * (o >> 2) + (o & 3)];
 #pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            if constexpr (!MATCHED) {
-                                const bool c1 = ku[s].b1 != ou[s].b1, c2 = ku[s].b2 != ou[s].b2;
-                                const uint32_t demoted = ku[s].b2 == ou[s].b1 ? ou[s].t1 : tile_id;
-                                ku[s].t2 = c1 ? demoted : (c2 ? tile_id : ou[s].t2);
-                                ku[s].t1 = c1 ? tile_id : ou[s].t1;
-                            } else {
+                                for (int s = 0; s < S; ++s) {
+                                    const uint32_t key = pack_key(acc[s][o], o);
+                                    const bool match = cls == lab[s];                 // helpers.rs:113 / :122
+                                    const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
+                                    km[s].p = kmin(km[s].p, kp);
+                                    km[s].n = kmin(km[s].n, kn);
+                                }
+                            });
+#pragma unroll
+                            for (int s = 0; s < S; ++s) {
                                 km[s].tp = km[s].p != om[s].p ? tile_id : om[s].tp;
                                 km[s].tn = km[s].n != om[s].n ? tile_id : om[s].tn;
                             }
@@ -566,10 +635,10 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                         f = ku[s].b1; fi = k1;
                         if (keyless(pb1, pk1, ku[s].b2, k2)) { sd = pb1; si = pk1; } else { sd = ku[s].b2; si = k2; }
                     }
-                    if (f < KEY_VALID_BELOW && !rescan) {
+                    if (key_valid(f) && !rescan) {
                         const float d1 = measure(fi);
                         wp.d = d1; wp.i = fi;
-                        if (sd < KEY_VALID_BELOW) {
+                        if (key_valid(sd)) {
                             const float d2 = measure(si);
                             if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
                         }
@@ -582,11 +651,11 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a, const u
                     const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
                     if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
                     if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
-                    if (p < KEY_VALID_BELOW) {
+                    if (key_valid(p)) {
                         wp.d = measure(kp); wp.i = kp;
                         rescan |= !(wp.d < INFINITY);
                     }
-                    if (n < KEY_VALID_BELOW) {
+                    if (key_valid(n)) {
                         wn.d = measure(kn); wn.i = kn;
                         rescan |= !(wn.d < INFINITY);
                     }
@@ -681,14 +750,11 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
         }
         Top2 top[S];
         Best1 pos[S], neg[S];
-        float zero_shift[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) zero_shift[s] = 0.0f;
 
         for (uint32_t t = 0; t < ntiles; ++t) {
             const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
             f32x16 acc[S];
-            tile_mma<R, S>(tile, xf, acc, zero_shift, s_col, h);
+            tile_mma<R, S>(tile, xf, acc, s_col, h);
             const uint32_t kbase = t * 32 + 4 * h;
             const uint32_t *tcls = (const uint32_t *)(tile + Gm::W_FLOATS) + 32;
 #pragma unroll
@@ -717,10 +783,10 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
             if (!MATCHED) {
                 top[s].merge_halves();
                 const Top2 &t = top[s];
-                if (t.b1 < INFINITY) {
+                if (t.b1 < KEY_VALID_F) {
                     const float d1 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i1, h));
                     wp.d = d1; wp.i = t.i1;
-                    if (t.b2 < INFINITY) {
+                    if (t.b2 < KEY_VALID_F) {
                         const float d2 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i2, h));
                         if (lexless(d2, t.i2, d1, t.i1)) { wp.d = d2; wp.i = t.i2; }
                     }
@@ -729,11 +795,11 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
             } else {
                 pos[s].merge_halves();
                 neg[s].merge_halves();
-                if (pos[s].d < INFINITY) {
+                if (pos[s].d < KEY_VALID_F) {
                     wp.d = sqrtf(exact_sq_lds<R>(xf[s], img, pos[s].i, h)); wp.i = pos[s].i;
                     rescan |= pos[s].d == -INFINITY || !(wp.d < INFINITY);
                 }
-                if (neg[s].d < INFINITY) {
+                if (neg[s].d < KEY_VALID_F) {
                     wn.d = sqrtf(exact_sq_lds<R>(xf[s], img, neg[s].i, h)); wn.i = neg[s].i;
                     rescan |= neg[s].d == -INFINITY || !(wn.d < INFINITY);
                 }
@@ -772,21 +838,21 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 //   * the two waves of a SIMD do not share the matrix pipe evenly, so batches are claimed from a
 //     queue instead of being dealt out.
 //
-// Packed keys.  The accumulator of a (weight tile, sample tile) starts at ||w_k||^2 + c with
-// c = ||x||^2 (1 + 2^-8) + tiny, so a finished score is ||x - w_k||^2 + (c - ||x||^2) > 0 and its f32
-// bit pattern orders like an unsigned integer.  The low 4 mantissa bits are replaced by the row's
-// position o among the lane's 16 rows of the tile; v_min_u32 / v_med3_u32 keep the best two keys
-// of a lane, and which TILE they came from is settled once per tile by comparing the pair before
-// and after.  Equal scores keep the lower index at every level (o inside a tile, the older tile
-// across tiles, the lower k across the lane pair), NaN / -INF / pad-row (+INF) patterns sort above
-// every finite score, and the two candidates are re-measured exactly as before.  Samples whose
-// ||x||^2 is not safely finite go to the exact in-order scan.
-// On entry:  acc = accumulator-init column of `tile` (+ c), a0 = this lane's chunk 0 of `tile`,
+// Packed keys.  A finished score is ||w_k||^2 - 2 x.w_k (the accumulator starts at the ||w_k||^2 column of
+// the tile).  The low 4 mantissa bits of its f32 pattern are replaced by the row's position o among the
+// lane's 16 rows of the tile, and the patterns are compared as floats: v_min_f32 / v_med3_f32 keep the
+// best two keys of a lane (3 VALU per score, no shift of the scores to one sign), and which TILE they
+// came from is settled once per tile by comparing the pair before and after.  Scores closer than the 4
+// dropped bits are ordered by o, not by value or index: both candidates are re-measured exactly and
+// compared like helpers.rs:70 where they are close, and exact ties between identical rows are settled by
+// settle_ties.  Pad rows score PAD_SCORE; samples whose ||x||^2 is not safely finite (the only source of
+// NaN / INF scores) go to the exact in-order scan.
+// On entry:  acc = accumulator-init column of `tile`, a0 = this lane's chunk 0 of `tile`,
 //            prev = finished scores of tile number `tprev_id` (class ids in tprev's tail).
-// On exit:   acc = scores of (tile, xf), prev = init column of `next` (+ c), a0 = chunk 0 of `next`.
+// On exit:   acc = scores of (tile, xf), prev = init column of `next`, a0 = chunk 0 of `next`.
 template <int R, bool MATCHED>
 __device__ __forceinline__ void half_step(const float *tile, const float *next, const float *tprev, uint32_t tprev_id,
-                                          uint32_t label, float c, const f32x4 (&xf)[R / 8], f32x16 &acc, f32x16 &prev,
+                                          uint32_t label, const f32x4 (&xf)[R / 8], f32x16 &acc, f32x16 &prev,
                                           f32x4 &a0, int row, int h, Keys2 &ku, KeysM &km)
 {
     using Gm = Geom<R>;
@@ -812,32 +878,27 @@ __device__ __forceinline__ void half_step(const float *tile, const float *next, 
                 a0 = *(const f32x4 *)(next + Gm::chunk_off(row, h));
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[e], xf[j][e], acc, 0, 0, 0);
-        constexpr int o0 = i * 16 / SPAN < 16 ? i * 16 / SPAN : 16;
-        constexpr int o1 = (i + 1) * 16 / SPAN < 16 ? (i + 1) * 16 / SPAN : 16;
-        static_for<o0, o1>([&](auto oo) {
-            constexpr int o = decltype(oo)::value;
-            const uint32_t key = pack_key(prev[o], o);
-            if constexpr (!MATCHED) {
-                ku.b2 = umed3(ku.b1, ku.b2, key);             // second smallest of {b1 <= b2, key}
-                ku.b1 = ku.b1 < key ? ku.b1 : key;
-            } else {
+        if constexpr (!MATCHED) {
+            if constexpr (i == 0) {                       // behind the first MFMA: prev's own MFMAs are long done
+                screen16(prev, ku);
+                settle_tiles(ku, ou, tprev_id);
+            }
+        } else {
+            constexpr int o0 = i * 16 / SPAN < 16 ? i * 16 / SPAN : 16;
+            constexpr int o1 = (i + 1) * 16 / SPAN < 16 ? (i + 1) * 16 / SPAN : 16;
+            static_for<o0, o1>([&](auto oo) {
+                constexpr int o = decltype(oo)::value;
+                const uint32_t key = pack_key(prev[o], o);
                 if constexpr ((o & 3) == 0) {
                     cgc = cgn;
                     if constexpr (o + 4 < 16) cgn = *(const u32x4 *)(tcls + 8 * ((o >> 2) + 1));
                 }
                 const bool match = cgc[o & 3] == label;           // helpers.rs:113 / :122
-                const uint32_t kp = match ? key : 0xFFFFFFFFu, kn = match ? 0xFFFFFFFFu : key;
-                km.p = km.p < kp ? km.p : kp;
-                km.n = km.n < kn ? km.n : kn;
-            }
-        });
-        if constexpr (o0 < 16 && o1 == 16) {              // all 16 keys of the tile are in: settle the tiles
-            if constexpr (!MATCHED) {
-                const bool c1 = ku.b1 != ou.b1, c2 = ku.b2 != ou.b2;
-                const uint32_t demoted = ku.b2 == ou.b1 ? ou.t1 : tprev_id;
-                ku.t2 = c1 ? demoted : (c2 ? tprev_id : ou.t2);
-                ku.t1 = c1 ? tprev_id : ou.t1;
-            } else {
+                const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
+                km.p = kmin(km.p, kp);
+                km.n = kmin(km.n, kn);
+            });
+            if constexpr (o0 < 16 && o1 == 16) {          // all 16 keys of the tile are in: settle the tiles
                 km.tp = km.p != om.p ? tprev_id : om.tp;
                 km.tn = km.n != om.n ? tprev_id : om.tn;
             }
@@ -847,8 +908,8 @@ __device__ __forceinline__ void half_step(const float *tile, const float *next, 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
-                cnext[4 * g + 0] = ci[0] + c; cnext[4 * g + 1] = ci[1] + c;
-                cnext[4 * g + 2] = ci[2] + c; cnext[4 * g + 3] = ci[3] + c;
+                cnext[4 * g + 0] = ci[0]; cnext[4 * g + 1] = ci[1];
+                cnext[4 * g + 2] = ci[2]; cnext[4 * g + 3] = ci[3];
             }
         }
     });
@@ -863,25 +924,18 @@ __device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tpr
     const uint32_t *tcls = (const uint32_t *)(tprev + Geom<R>::W_FLOATS) + 32 + 4 * h;
     const Keys2 ou = ku;
     const KeysM om = km;
-    static_for<0, 16>([&](auto oo) {
-        constexpr int o = decltype(oo)::value;
-        const uint32_t key = pack_key(prev[o], o);
-        if constexpr (!MATCHED) {
-            ku.b2 = umed3(ku.b1, ku.b2, key);
-            ku.b1 = ku.b1 < key ? ku.b1 : key;
-        } else {
-            const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;
-            const uint32_t kp = match ? key : 0xFFFFFFFFu, kn = match ? 0xFFFFFFFFu : key;
-            km.p = km.p < kp ? km.p : kp;
-            km.n = km.n < kn ? km.n : kn;
-        }
-    });
-    if (!MATCHED) {
-        const bool c1 = ku.b1 != ou.b1, c2 = ku.b2 != ou.b2;
-        const uint32_t demoted = ku.b2 == ou.b1 ? ou.t1 : tprev_id;
-        ku.t2 = c1 ? demoted : (c2 ? tprev_id : ou.t2);
-        ku.t1 = c1 ? tprev_id : ou.t1;
+    if constexpr (!MATCHED) {
+        screen16<1>(prev, ku);
+        settle_tiles(ku, ou, tprev_id);
     } else {
+        static_for<0, 16>([&](auto oo) {
+            constexpr int o = decltype(oo)::value;
+            const uint32_t key = pack_key(prev[o], o);
+            const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;
+            const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
+            km.p = kmin(km.p, kp);
+            km.n = kmin(km.n, kn);
+        });
         km.tp = km.p != om.p ? tprev_id : om.tp;
         km.tn = km.n != om.n ? tprev_id : om.tn;
     }
@@ -911,16 +965,16 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
             f = ku.b1; fi = k1;
             if (keyless(pb1, pk1, ku.b2, k2)) { sd = pb1; si = pk1; } else { sd = ku.b2; si = k2; }
         }
-        if (f < KEY_VALID_BELOW && !unsafe) {
+        if (key_valid(f) && !unsafe) {
             const float d1 = dist(fi);
             wp.d = d1; wp.i = fi;
             // The runner-up is re-measured only where it can still win: a key differs from the true
-            // ||x-w||^2 + (c - ||x||^2) by less than margin/2 (f32 accumulation of 2 x.w, rounding of the
+            // ||w||^2 - 2 x.w by less than margin/2 (f32 accumulation of 2 x.w, rounding of the
             // init column, the 4 truncated bits), so a gap above `margin` decides the order already.
             // Decided per wave: the re-measurement is 80 VALU + 16 LDS reads for every lane or for none.
-            const bool close = sd < KEY_VALID_BELOW && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
+            const bool close = key_valid(sd) && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
             if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
-                if (sd < KEY_VALID_BELOW) {
+                if (key_valid(sd)) {
                     const float d2 = dist(si);
                     if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
                 }
@@ -934,11 +988,11 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
         if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
         if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
-        if (p < KEY_VALID_BELOW) {
+        if (key_valid(p)) {
             wp.d = dist(kp); wp.i = kp;
             unsafe |= !(wp.d < INFINITY);
         }
-        if (n < KEY_VALID_BELOW) {
+        if (key_valid(n)) {
             wn.d = dist(kn); wn.i = kn;
             unsafe |= !(wn.d < INFINITY);
         }
@@ -1089,10 +1143,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 ci = *(const f32x4 *)(img + Gm::W_FLOATS + 8 * g + 4 * h);
-            acc0[4 * g + 0] = ci[0] + c; acc0[4 * g + 1] = ci[1] + c; acc0[4 * g + 2] = ci[2] + c; acc0[4 * g + 3] = ci[3] + c;
+            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = INFINITY;             // "tile -1": its keys never win
+        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;             // "tile -1": its keys never win
         const float *tprev = img;
         uint32_t tid = 0;
         for (uint32_t t = 0; t < ntiles; t += 2) {
@@ -1100,9 +1154,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             const float *tile1 = tile + Gm::TILE_FLOATS;
             const float *next = t + 2 < ntiles ? tile1 + Gm::TILE_FLOATS : img;
             // tile t computes into acc0 while tile t-1 (in acc1) is screened; acc1 leaves as the init column of t+1
-            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, c, xf, acc0, acc1, a0, s_col, h, ku, km);
+            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, xf, acc0, acc1, a0, s_col, h, ku, km);
             // tile t+1 computes into acc1 while tile t (in acc0) is screened; acc0 leaves as the init column of t+2
-            half_step<R, MATCHED>(tile1, next, tile, t, label, c, xf, acc1, acc0, a0, s_col, h, ku, km);
+            half_step<R, MATCHED>(tile1, next, tile, t, label, xf, acc1, acc0, a0, s_col, h, ku, km);
             tprev = tile1;
             tid = t + 1;
         }
@@ -1302,18 +1356,18 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
-            acc0[4 * g + 0] = ci[0] + c; acc0[4 * g + 1] = ci[1] + c; acc0[4 * g + 2] = ci[2] + c; acc0[4 * g + 3] = ci[3] + c;
+            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = INFINITY;
+        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;
         const float *tprev = img;
         uint32_t tid = 0;
         for (uint32_t t = 0; t < ntiles; t += 2) {
             const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
             const float *tile1 = tile + Gs::TILE_FLOATS;
             const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
-            half_step<16, MATCHED>(tile, tile1, tprev, tid, label, c, yf, acc0, acc1, a0, s_col, h, ku, km);
-            half_step<16, MATCHED>(tile1, next, tile, t, label, c, yf, acc1, acc0, a0, s_col, h, ku, km);
+            half_step<16, MATCHED>(tile, tile1, tprev, tid, label, yf, acc0, acc1, a0, s_col, h, ku, km);
+            half_step<16, MATCHED>(tile1, next, tile, t, label, yf, acc1, acc0, a0, s_col, h, ku, km);
             tprev = tile1;
             tid = t + 1;
         }
@@ -1486,18 +1540,18 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
-            acc0[4 * g + 0] = ci[0] + c; acc0[4 * g + 1] = ci[1] + c; acc0[4 * g + 2] = ci[2] + c; acc0[4 * g + 3] = ci[3] + c;
+            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = INFINITY;
+        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;
         const float *tprev = img;
         uint32_t tid = 0;
         for (uint32_t t = 0; t < ntiles; t += 2) {
             const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
             const float *tile1 = tile + Gs::TILE_FLOATS;
             const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
-            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, c, yf, acc0, acc1, a0, s_col, h, ku, km);
-            half_step<R, MATCHED>(tile1, next, tile, t, label, c, yf, acc1, acc0, a0, s_col, h, ku, km);
+            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, yf, acc0, acc1, a0, s_col, h, ku, km);
+            half_step<R, MATCHED>(tile1, next, tile, t, label, yf, acc1, acc0, a0, s_col, h, ku, km);
             tprev = tile1;
             tid = t + 1;
         }
@@ -1711,7 +1765,7 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
 {
     if (m.R1 != (uint32_t)R1) return false;
     // an even number of tiles: the pipelined kernel ping-pongs two accumulators (pad rows score +INF)
-    img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
+    img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
                            m.ngroups1, ((size_t)m.K + 63) / 64 * 64);
     bind<MODE_EUCLID, R1, R1, (R1 >= 128 ? 1 : 2)>(m);
     if constexpr (R1 < 256) {
@@ -1736,7 +1790,7 @@ bool bind_omega(EngineModel &m, std::vector<float> &img1, std::vector<float> &im
 {
     if (m.R1 != (uint32_t)R1 || m.R2 != (uint32_t)R2) return false;
     img1 = build_images<R1>(Om.data(), m.M, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, m.ngroups1, R2 >= 32 ? R2 : 32);
-    img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), INFINITY,
+    img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
                             m.ngroups2);
     bind<MODE_OMEGA, R1, R2, 1>(m);
     return true;
@@ -1760,7 +1814,7 @@ bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &
             }
     uint32_t ngroups2 = 0;
     std::vector<float> pimg = build_images<16>(Pp.data(), m.K, 16, 16, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
-                                               INFINITY, ngroups2);
+                                               PAD_SCORE, ngroups2);
     if (pimg.size() * sizeof(float) + (size_t)16 * ROWF * sizeof(float) > (size_t)RES_BYTES) return false;
     img2 = std::move(pimg);
     m.ngroups2 = ngroups2;
@@ -1783,7 +1837,7 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     if (m.D != (uint32_t)R || m.R2 != (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;
     uint32_t ngroups2 = 0;
     std::vector<float> pimg = build_images<R>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
-                                              INFINITY, ngroups2, ((size_t)m.K + 63) / 64 * 64);
+                                              PAD_SCORE, ngroups2, ((size_t)m.K + 63) / 64 * 64);
     if (pimg.size() * sizeof(float) > (size_t)RES_BYTES) return false;
     img2 = std::move(pimg);
     m.ngroups2 = ngroups2;
