@@ -14,7 +14,7 @@ k+1 (the kernel claims its batches from a queue, so CUs the gather occupies at l
 their share of the work).  All gathers have completed before the timed region ends.
 
 One JSON line on rank 0: the contract fields plus
-  roofline     dominant kernel (k_resident_pipe for c2; k_engine otherwise) against the f32 MFMA peak: algorithmic flops per launch
+  roofline     dominant kernel (k_resident_pipe for c2, k_omega_pipe c3, k_lowrank_pipe c4, k_engine c5) against the f32 MFMA peak: algorithmic flops per launch
                (2*K*D per sample) / mean launch time from HIP events on the launch stream
   cpu_baseline the f64 oracle (a C port of the reference's loops; the Rust reference cannot be built
                here) timed on a bounded sample on this box's host cores, rank 0, N=1 only.
@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
 # device function behind each kernel family name reported by vqhip_last_kernel
-KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "scalar": "k_assign_scalar"}
+KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "mfma_omega_lds": "k_omega_pipe",
+             "mfma_omega_lowrank_lds": "k_lowrank_pipe", "scalar": "k_assign_scalar"}
 
 
 def flops_per_sample(cfg):

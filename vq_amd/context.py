@@ -195,6 +195,18 @@ class Context:
             self._chk(self._L.vqhip_assign_matched_device(self._h, p(X), p(y), N, p(idx_out), p(dist_out),
                                                           p(jneg_out), p(dneg_out), stream))
 
+    def project_into(self, X, Y_out, which: int = _lib.PROJECT_LAMBDA):
+        """Device path of project / project_omega: X and Y_out are torch tensors on the GPU (N x D -> N x D or N x M)."""
+        import torch
+
+        self._check_torch(X)
+        width = self.M if which == _lib.PROJECT_OMEGA else self.D
+        if tuple(Y_out.shape) != (X.shape[0], width) or Y_out.dtype != torch.float32 or not Y_out.is_contiguous():
+            raise ValueError("Y_out must be a contiguous float32 N x %d tensor" % width)
+        stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+        self._chk(self._L.vqhip_project_device(self._h, C.c_void_p(X.data_ptr()), X.shape[0], int(which),
+                                               C.c_void_p(Y_out.data_ptr()), stream))
+
     def _assign_torch(self, X, y, want_dist):
         import torch
 

@@ -49,6 +49,8 @@ struct vqhip_ctx {
     EngineModel *engine = nullptr;
     bool engine_tried = false;
     std::string engine_why;
+    ProjectModel *proj_omega = nullptr, *proj_lambda = nullptr;   // matrix-core projections (global Omega)
+    bool proj_tried = false;
 
     Staging st[2];
     size_t st_chunk = 0;       // samples per staging buffer
@@ -80,6 +82,10 @@ void drop_engine(vqhip_ctx *c)
     c->engine = nullptr;
     c->engine_tried = false;
     c->engine_why.clear();
+    project_free(c->proj_omega);
+    project_free(c->proj_lambda);
+    c->proj_omega = c->proj_lambda = nullptr;
+    c->proj_tried = false;
 }
 
 void free_staging(vqhip_ctx *c)
@@ -285,11 +291,45 @@ int check_project(vqhip_ctx *c, int which)
     return VQHIP_OK;
 }
 
+// Images of Omega and of Lambda = Omega^T Omega (f64, rounded once: the reference builds Lambda first and
+// multiplies every sample by it, gmlvq.rs:357-366) for the matrix-core projection kernel.
+int prepare_project(vqhip_ctx *c)
+{
+    if (c->proj_tried || c->policy == VQHIP_KERNEL_SCALAR || c->omega_kind != OMEGA_GLOBAL) return VQHIP_OK;
+    c->proj_tried = true;
+    hipError_t herr = hipSuccess;
+    c->proj_omega = project_build(c->hOm, c->M, c->D, herr);
+    if (herr != hipSuccess) return c->fail_hip(herr, "project_build");
+    if (!c->proj_omega) return VQHIP_OK;
+    const uint32_t D = c->D, M = c->M;
+    std::vector<float> lam((size_t)D * D);
+    for (uint32_t i = 0; i < D; ++i)
+        for (uint32_t j = i; j < D; ++j) {
+            double t = 0.0;
+            for (uint32_t m = 0; m < M; ++m) t += (double)c->hOm[(size_t)m * D + i] * (double)c->hOm[(size_t)m * D + j];
+            lam[(size_t)i * D + j] = lam[(size_t)j * D + i] = (float)t;
+        }
+    c->proj_lambda = project_build(lam, D, D, herr);
+    if (herr != hipSuccess) return c->fail_hip(herr, "project_build");
+    return VQHIP_OK;
+}
+
 // One device-resident batch of project / project_omega, enqueued on `s`.
 int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *dY, hipStream_t s)
 {
     int rc = check_project(c, which);
     if (rc != VQHIP_OK || N == 0) return rc;
+    if ((rc = prepare_project(c)) != VQHIP_OK) return rc;
+    if (c->omega_kind == OMEGA_GLOBAL && c->policy != VQHIP_KERNEL_SCALAR) {
+        const ProjectModel *pm = which == VQHIP_PROJECT_OMEGA ? c->proj_omega : c->proj_lambda;
+        const uint32_t ldy = project_width(c, which);
+        if (pm && ldy % 4 == 0 && ((uintptr_t)dY & 15) == 0 && ((uintptr_t)dX & 15) == 0) {
+            c->last_kernel = "mfma_project";
+            HIPCHK(c, project_run(pm, dX, N, dY, ldy, s));
+            return VQHIP_OK;
+        }
+    }
+    c->last_kernel = "scalar_project";
     if (c->omega_kind == OMEGA_GLOBAL && which == VQHIP_PROJECT_OMEGA) {          // liramlvq.rs:429-446
         HIPCHK(c, launch_project_scalar(dX, N, c->D, c->dOm, c->M, dY, s));
         return VQHIP_OK;

@@ -74,6 +74,12 @@ const char *engine_name(const EngineModel *m);
 hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out,
                          hipStream_t s);
 
+// Y = X . A^T on the matrix cores for an A (rows x D) resident in LDS; nullptr when D is not 32/64/128/256.
+struct ProjectModel;
+ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t D, hipError_t &herr);
+void project_free(ProjectModel *m);
+hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float *dY, uint32_t ldy, hipStream_t s);
+
 // ---------------------------------------------------------------- synth (synth.hip)
 hipError_t launch_synth_fill(float *dout, uint64_t count, uint64_t first, uint64_t seed, uint32_t stream_id,
                              float scale, const float *dbase, uint64_t base_len, hipStream_t s);
