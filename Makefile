@@ -10,8 +10,9 @@ OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_mfma.o $(CSRC
 LIB      := vq_amd/libvqhip.so
 
 MODELS_TEST := tests/cpp/test_models
+ROWS_BENCH  := tools/host_rows_bench
 
-all: $(LIB) oracle $(MODELS_TEST)
+all: $(LIB) oracle $(MODELS_TEST) $(ROWS_BENCH)
 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
@@ -26,11 +27,15 @@ $(CSRC)/%.o: $(CSRC)/%.cpp $(CSRC)/vq_common.h $(CSRC)/engine.h include/vqhip.h
 $(MODELS_TEST): tests/cpp/test_models.cpp include/vq_models.hpp include/vqhip.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ -Lvq_amd -lvqhip -Wl,-rpath,'$$ORIGIN/../../vq_amd'
 
+# native timing of the host-pointer entry points (PCIe-inclusive)
+$(ROWS_BENCH): tools/host_rows_bench.cpp include/vqhip.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ -Lvq_amd -lvqhip -Wl,-rpath,'$$ORIGIN/../vq_amd'
+
 oracle:
 	$(MAKE) -C oracle -s libvqoracle.so
 
 clean:
-	rm -f $(OBJS) $(LIB) $(MODELS_TEST)
+	rm -f $(OBJS) $(LIB) $(MODELS_TEST) $(ROWS_BENCH)
 	$(MAKE) -C oracle -s clean
 
 .PHONY: all oracle clean
