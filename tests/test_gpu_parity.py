@@ -259,6 +259,34 @@ def test_host_path_multi_chunk(ctx):
         assert rep.ok, str(rep)
 
 
+def test_host_path_multi_chunk_shared_scratch_and_queues(ctx):
+    """Chunks alternate between two streams: the scalar Omega path shares one projection scratch buffer
+    between them, the MFMA kernels one set of batch counters.  Every chunk must come out whole."""
+    m = _model(("t", "LiRaMLVQ", 1, 10, 6, 3, "global"))              # D = 10: scalar kernels, 3.3M-row chunks
+    N = (128 << 20) // 40 * 2 + 4321
+    X = synth.samples_host(m, 0, N)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    synth.load_model(ctx, m, with_labels=False)
+    idx, dist = ctx.assign(X)
+    assert ctx.last_kernel == "scalar"
+    for lo in (0, N // 3, N // 2 - 300, N - 2000):
+        o = oracle.assign(X[lo:lo + 2000], m.W, omega=m.omega, threads=8)
+        rep = parity.compare(idx[lo:lo + 2000], dist[lo:lo + 2000], *o, atol=2e-6)
+        assert rep.ok, f"rows {lo}..: {rep}"
+    m = _model(("t", "GLVQ", 1, 16, 40, 0, "none"))                   # D = 16: pipelined kernel, 2M-row chunks
+    N = (128 << 20) // 64 * 3 + 99
+    X = synth.samples_host(m, 0, N)
+    synth.load_model(ctx, m, with_labels=False)
+    idx, dist = ctx.assign(X)
+    assert ctx.last_kernel == "mfma_euclid_lds_pipe"
+    ref_idx, ref_dist = ctx.assign(X[: N // 7])                        # one chunk: no overlap possible
+    assert (idx[: N // 7] == ref_idx).all() and (dist[: N // 7] == ref_dist).all()
+    for lo in (N // 3 - 1000, 2 * (N // 3), N - 2000):
+        o = oracle.assign(X[lo:lo + 2000], m.W, threads=8)
+        rep = parity.compare(idx[lo:lo + 2000], dist[lo:lo + 2000], *o)
+        assert rep.ok, f"rows {lo}..: {rep}"
+
+
 # ------------------------------------------------------------------ ties at scale (packed-key screening)
 
 @pytest.mark.parametrize("copies", [(64, 4), (50, 5)], ids=["4x64", "5x50"])

@@ -45,6 +45,9 @@ struct vqhip_ctx {
     size_t dProj_cap = 0;
     float *dYproj = nullptr;   // scalar-path scratch: projected samples, chunk x M
     size_t dYproj_cap = 0;
+    // The scratch buffers are shared by every stream the context is driven from (the host path alternates
+    // two): the last kernel that uses one records this event, the next user waits for it on its stream.
+    hipEvent_t scratch_done = nullptr;
 
     EngineModel *engine = nullptr;
     bool engine_tried = false;
@@ -141,6 +144,22 @@ int prepare_engine(vqhip_ctx *c)
     return VQHIP_OK;
 }
 
+int scratch_acquire(vqhip_ctx *c, hipStream_t s)
+{
+    if (!c->scratch_done) {
+        HIPCHK(c, hipEventCreateWithFlags(&c->scratch_done, hipEventDisableTiming));
+        return VQHIP_OK;
+    }
+    HIPCHK(c, hipStreamWaitEvent(s, c->scratch_done, 0));
+    return VQHIP_OK;
+}
+
+int scratch_release(vqhip_ctx *c, hipStream_t s)
+{
+    HIPCHK(c, hipEventRecord(c->scratch_done, s));
+    return VQHIP_OK;
+}
+
 // All kernels for one device-resident batch, enqueued on `s`.
 int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s)
 {
@@ -170,6 +189,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
             HIPCHK(c, hipMalloc((void **)&c->dYproj, chunk * c->M * sizeof(float)));
             c->dYproj_cap = chunk * c->M;
         }
+        if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
         for (uint64_t off = 0; off < N; off += chunk) {
             const uint64_t n = std::min(chunk, N - off);
             Outputs o = out;
@@ -181,6 +201,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
             HIPCHK(c, launch_assign_scalar(c->dYproj, n, c->M, c->dP, c->K, c->dcls, dy ? dy + off : nullptr,
                                            /*rooted=*/false, o, s));
         }
+        if ((rc = scratch_release(c, s)) != VQHIP_OK) return rc;
     } else {
         HIPCHK(c, launch_assign_local_scalar(dX, N, c->D, c->dW, c->K, c->dOm, c->M, c->dcls, dy, out, s));
     }
@@ -347,6 +368,7 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
     }
     float *dT = c->dProj;
     uint32_t *dwin = (uint32_t *)(c->dProj + (size_t)chunk * c->M);
+    if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
     for (uint64_t off = 0; off < N; off += chunk) {
         const uint64_t n = std::min(chunk, N - off);
         const float *x = dX + off * c->D;
@@ -360,7 +382,7 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
             HIPCHK(c, launch_project_local(x, n, c->D, c->dOm, c->M, dwin, dT, y, s));
         }
     }
-    return VQHIP_OK;
+    return scratch_release(c, s);
 }
 
 Packer contiguous_f32(const vqhip_ctx *c, const float *X)
@@ -479,6 +501,7 @@ int vqhip_destroy(vqhip_ctx *c)
     (void)hipFree(c->dcls);
     (void)hipFree(c->dYproj);
     (void)hipFree(c->dProj);
+    if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
     delete c;
     return VQHIP_OK;
 }

@@ -1713,12 +1713,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
 }
 
 // ------------------------------------------------------------------------------ host side
+constexpr uint32_t QUEUE_SLOTS = 16, QUEUE_STRIDE = 16;     // 16 counters, 64 bytes apart
+
 struct EngineModel {
     int mode = MODE_EUCLID;
     uint32_t K = 0, D = 0, M = 0, R1 = 0, R2 = 0, tiles_per_proto = 0;
     bool has_cls = false;
     float *img1 = nullptr, *img2 = nullptr, *plain = nullptr;
-    uint32_t *cls = nullptr, *queue = nullptr;
+    uint32_t *cls = nullptr;
+    // Batch counters, one per launch in flight: launches of one model on different streams (the two staging
+    // streams of the host path) may overlap at their edges, and a launch that zeroed the counter of the
+    // one still running would hand its batches to it.  Slots are used round-robin.
+    uint32_t *queue = nullptr;
+    mutable uint32_t next_slot = 0;
     uint32_t *dup_first = nullptr, *dup_next = nullptr;     // identical search-space rows (null: none)
     uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
     const char *name = "mfma";
@@ -1811,7 +1818,7 @@ hipError_t launch_t(const EngineModel &m, const EngineArgs &a, bool matched, hip
 {
     const uint64_t cap = 256ull * WPS;                                // 256 CUs x workgroups per CU
     const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
-    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS>), dim3(grid), dim3(256), 0, st, a, m.cls);
@@ -1844,7 +1851,7 @@ hipError_t launch_resident_pipe(const EngineModel &m, const EngineArgs &a, bool 
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (DIAG && getenv("VQHIP_NW4"))
         hipLaunchKernelGGL((k_resident_pipe<R, false, true, 4>), dim3(grid), dim3(256), 0, st, a);
@@ -1862,7 +1869,7 @@ hipError_t launch_lowrank(const EngineModel &m, const EngineArgs &a, bool matche
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_lowrank_pipe<R1, true>), dim3(grid), dim3(512), 0, st, a);
@@ -1876,7 +1883,7 @@ hipError_t launch_omega_pipe(const EngineModel &m, const EngineArgs &a, bool mat
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(m.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_omega_pipe<R, true>), dim3(grid), dim3(512), 0, st, a);
@@ -2117,7 +2124,7 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
     if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
     if (herr == hipSuccess && !dup_first.empty()) herr = to_device(&out->dup_first, dup_first);
     if (herr == hipSuccess && !dup_next.empty()) herr = to_device(&out->dup_next, dup_next);
-    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, sizeof(uint32_t));
+    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, QUEUE_SLOTS * QUEUE_STRIDE * sizeof(uint32_t));
     if (herr != hipSuccess) {
         engine_free(out);
         return nullptr;
@@ -2159,7 +2166,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
-    a.queue = m->queue;
+    a.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
     a.dup_first = m->dup_first;
     a.dup_next = m->dup_next;
     a.cls = m->cls;
@@ -2200,7 +2207,8 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
 struct ProjectModel {
     uint32_t rows = 0, D = 0, R = 0, ntiles = 0, tile_floats = 0, tiles_per_launch = 0;
     float *img = nullptr;
-    uint32_t *queue = nullptr;
+    uint32_t *queue = nullptr;                       // QUEUE_SLOTS counters, as in EngineModel
+    mutable uint32_t next_slot = 0;
     hipError_t (*launch)(const ProjectArgs &, hipStream_t) = nullptr;
 };
 
@@ -2242,7 +2250,7 @@ ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t
         return nullptr;
     ProjectModel *out = new ProjectModel(m);
     herr = to_device(&out->img, img);
-    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, sizeof(uint32_t));
+    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, QUEUE_SLOTS * QUEUE_STRIDE * sizeof(uint32_t));
     if (herr != hipSuccess) {
         project_free(out);
         return nullptr;
@@ -2269,7 +2277,7 @@ hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float
         a.ntiles = std::min(m->tiles_per_launch, m->ntiles - t0);
         a.Y = dY; a.ldy = ldy; a.col0 = t0 * 32u; a.out_dim = m->rows;
         a.nbatches = (N + 31) / 32;
-        a.queue = m->queue;
+        a.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
         const hipError_t e = m->launch(a, s);
         if (e != hipSuccess) return e;
     }
