@@ -1,0 +1,383 @@
+// Model builder of the MFMA kernels (host side): tile images in the geometry of engine.h, kernel selection
+// by shape, and the launch of one pass.  The kernels live in kernels_engine.hip (streamed weights),
+// kernels_resident.hip (Euclidean, prototypes in LDS) and kernels_omega.hip (Omega models, prototypes in LDS).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "mfma_device.h"
+#include "mfma_images.h"
+
+namespace vq {
+
+struct EngineModel {
+    int mode = MODE_EUCLID;
+    uint32_t K = 0, D = 0, M = 0, R1 = 0, R2 = 0, tiles_per_proto = 0;
+    bool has_cls = false;
+    float *img1 = nullptr, *img2 = nullptr, *plain = nullptr;
+    uint32_t *cls = nullptr;
+    // Batch counters, one per launch in flight: launches of one model on different streams (the two staging
+    // streams of the host path) may overlap at their edges, and a launch that zeroed the counter of the
+    // one still running would hand its batches to it.  Slots are used round-robin.
+    uint32_t *queue = nullptr;
+    mutable uint32_t next_slot = 0;
+    uint32_t *dup_first = nullptr, *dup_next = nullptr;     // identical search-space rows (null: none)
+    uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
+    const char *name = "mfma";
+    LaunchFn launch = nullptr;
+    int samples_per_batch = 0;
+    float ss_limit = 0.0f, wmax2 = 0.0f;
+};
+
+namespace {
+
+int pad_pow2(uint32_t v, int lo)
+{
+    int r = lo;
+    while ((uint32_t)r < v) r <<= 1;
+    return r;
+}
+
+// Groups of prototypes with identical rows (-0 counted as +0): first / next tables for settle_ties, left
+// empty when every row is unique.
+void find_duplicates(const std::vector<float> &Q, uint32_t K, uint32_t L, std::vector<uint32_t> &first, std::vector<uint32_t> &next)
+{
+    std::vector<float> canon(Q.begin(), Q.begin() + (size_t)K * L);
+    for (float &v : canon) v += 0.0f;
+    auto row_cmp = [&](uint32_t x, uint32_t y) { return std::memcmp(&canon[(size_t)x * L], &canon[(size_t)y * L], L * sizeof(float)); };
+    std::vector<uint32_t> order(K);
+    for (uint32_t k = 0; k < K; ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const int c = row_cmp(x, y);
+        return c < 0 || (c == 0 && x < y);
+    });
+    bool any = false;
+    std::vector<uint32_t> f(K), n(K);
+    for (uint32_t i = 0; i < K;) {
+        uint32_t j = i + 1;
+        while (j < K && row_cmp(order[i], order[j]) == 0) ++j;
+        for (uint32_t t = i; t < j; ++t) {
+            f[order[t]] = order[i];
+            n[order[t]] = t + 1 < j ? order[t + 1] : order[t];
+        }
+        any |= j - i > 1;
+        i = j;
+    }
+    if (any) {
+        first = std::move(f);
+        next = std::move(n);
+    }
+}
+
+int variant_env()
+{
+    const char *v = getenv("VQHIP_VARIANT");     // experiments only: picks among co-compiled tilings
+    return v ? atoi(v) : 0;
+}
+
+template <int R1>
+bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<float> &W, const std::vector<float> &norms,
+                 const std::vector<uint32_t> &cls)
+{
+    if (m.R1 != (uint32_t)R1) return false;
+    // an even number of tiles: the pipelined kernel ping-pongs two accumulators (pad rows score +INF)
+    img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
+                           m.ngroups1, ((size_t)m.K + 63) / 64 * 64);
+    m.launch = streamed_launcher(MODE_EUCLID, R1, R1, &m.samples_per_batch);
+    if constexpr (R1 < 256) {
+        if ((size_t)m.ngroups1 * Geom<R1>::STAGE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
+            m.launch = resident_launcher(R1, &m.samples_per_batch);
+            m.name = "mfma_euclid_lds";
+            if (m.D == (uint32_t)R1 && !getenv("VQHIP_NO_PIPE")) {       // unpadded rows: the pipelined kernel
+                m.samples_per_batch = 32;
+                m.launch = resident_pipe_launcher(R1, variant_env() == 31);
+                m.name = "mfma_euclid_lds_pipe";
+            }
+        }
+    }
+    return true;
+}
+
+template <int R1, int R2>
+bool bind_omega(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
+                const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
+{
+    if (m.R1 != (uint32_t)R1 || m.R2 != (uint32_t)R2) return false;
+    img1 = build_images<R1>(Om.data(), m.M, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, m.ngroups1, R2 >= 32 ? R2 : 32);
+    img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
+                            m.ngroups2);
+    m.launch = streamed_launcher(MODE_OMEGA, R1, R2, &m.samples_per_batch);
+    return true;
+}
+
+// Omega with at most 16 rows, unpadded sample rows, both images resident in LDS: k_lowrank_pipe
+template <int R1>
+bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
+                  const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
+{
+    if (m.D != (uint32_t)R1 || m.M > 16 || getenv("VQHIP_NO_RESIDENT")) return false;
+    constexpr int ROWF = R1 + 4;
+    // p_k with chunks 1 and 2 swapped (see the kernel), zero padded to 16
+    std::vector<float> Pp((size_t)m.K * 16, 0.0f);
+    static const int actual_chunk[4] = {0, 2, 1, 3};
+    for (uint32_t k = 0; k < m.K; ++k)
+        for (int ci = 0; ci < 4; ++ci)
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t d = 4u * actual_chunk[ci] + e;
+                if (d < m.M) Pp[(size_t)k * 16 + 4 * ci + e] = P[(size_t)k * m.M + d];
+            }
+    uint32_t ngroups2 = 0;
+    std::vector<float> pimg = build_images<16>(Pp.data(), m.K, 16, 16, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
+                                               PAD_SCORE, ngroups2);
+    if (pimg.size() * sizeof(float) + (size_t)16 * ROWF * sizeof(float) > (size_t)RES_BYTES) return false;
+    img2 = std::move(pimg);
+    m.ngroups2 = ngroups2;
+    img1.assign((size_t)16 * ROWF, 0.0f);                              // Omega rows, row stride R1 + 4
+    for (uint32_t r = 0; r < m.M; ++r) std::memcpy(&img1[(size_t)r * ROWF], &Om[(size_t)r * m.D], m.D * sizeof(float));
+    m.ngroups1 = 1;
+    m.R1 = R1;
+    m.R2 = 16;
+    m.launch = lowrank_launcher(R1);
+    m.samples_per_batch = 32;
+    m.name = "mfma_omega_lowrank_lds";
+    return true;
+}
+
+// Omega padded to R x R with D == R, projected prototypes resident in LDS, Omega from L2: k_omega_pipe
+template <int R>
+bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
+                     const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
+{
+    if (m.D != (uint32_t)R || m.R2 != (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;
+    uint32_t ngroups2 = 0;
+    std::vector<float> pimg = build_images<R>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
+                                              PAD_SCORE, ngroups2, ((size_t)m.K + 63) / 64 * 64);
+    if (pimg.size() * sizeof(float) > (size_t)RES_BYTES) return false;
+    img2 = std::move(pimg);
+    m.ngroups2 = ngroups2;
+    // Omega as A-fragment pieces: piece (t, j), lane (row, h) = Omega[32 t + row][4 (2 j + h) .. + 3]
+    constexpr int NT = R / 32, NJ = R / 8;
+    img1.assign((size_t)NT * NJ * 64 * 4, 0.0f);
+    for (int t = 0; t < NT; ++t)
+        for (int j = 0; j < NJ; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const uint32_t row = 32u * t + (lane & 31), col = 4u * (2 * j + (lane >> 5));
+                if (row < m.M) std::memcpy(&img1[(((size_t)t * NJ + j) * 64 + lane) * 4], &Om[(size_t)row * m.D + col], 4 * sizeof(float));
+            }
+    m.ngroups1 = 1;
+    m.launch = omega_pipe_launcher(R);
+    m.samples_per_batch = 32;
+    m.name = "mfma_omega_lds";
+    return true;
+}
+
+template <int R1>
+bool bind_local(EngineModel &m, std::vector<float> &img, const std::vector<float> &Oms, const std::vector<float> &negp,
+                const std::vector<uint32_t> &cls)
+{
+    if (m.R1 != (uint32_t)R1) return false;
+    // every Omega_j padded to whole 32-row tiles, so a tile never straddles two prototypes
+    const uint32_t tpp = (m.M + 31) / 32, rows_pp = tpp * 32;
+    std::vector<float> rows((size_t)m.K * rows_pp * m.D, 0.0f), init((size_t)m.K * rows_pp, 0.0f);
+    std::vector<uint32_t> rcls((size_t)m.K * rows_pp, 0xFFFFFFFFu);
+    for (uint32_t j = 0; j < m.K; ++j)
+        for (uint32_t r = 0; r < rows_pp; ++r) {
+            const size_t o = (size_t)j * rows_pp + r;
+            if (r < m.M) {
+                std::memcpy(&rows[o * m.D], &Oms[((size_t)j * m.M + r) * m.D], m.D * sizeof(float));
+                init[o] = negp[(size_t)j * m.M + r];
+            }
+            if (!cls.empty()) rcls[o] = cls[j];
+        }
+    img = build_images<R1>(rows.data(), rows.size() / m.D, m.D, m.D, 1.0f, init.data(), rcls.data(), 0.0f, m.ngroups1);
+    m.tiles_per_proto = tpp;
+    m.launch = streamed_launcher(MODE_LOCAL, R1, R1, &m.samples_per_batch);
+    return true;
+}
+
+}  // namespace
+
+EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, const std::vector<float> &Om,
+                          int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, std::string &why,
+                          hipError_t &herr)
+{
+    herr = hipSuccess;
+    if (D % 4 != 0 || D > 256) {
+        why = "sample length must be a multiple of 4 and at most 256";
+        return nullptr;
+    }
+    if (omega_kind != OMEGA_NONE && M > 256) {
+        why = "Omega has more than 256 rows";
+        return nullptr;
+    }
+    EngineModel m;
+    m.K = K; m.D = D; m.M = M;
+    m.R1 = (uint32_t)pad_pow2(D, 16);
+    m.has_cls = !cls.empty();
+    std::vector<float> img1, img2, plain;
+    std::vector<uint32_t> dup_first, dup_next;
+    bool ok = false;
+
+    if (omega_kind == OMEGA_NONE || omega_kind == OMEGA_GLOBAL) {
+        // search space: the prototypes themselves, or their projections p_k = Omega w_k (f64, rounded once)
+        const uint32_t L = omega_kind == OMEGA_NONE ? D : M;
+        std::vector<float> P;
+        if (omega_kind == OMEGA_GLOBAL) {
+            P.resize((size_t)K * M);
+            for (uint32_t k = 0; k < K; ++k)
+                for (uint32_t r = 0; r < M; ++r) {
+                    double t = 0.0;
+                    for (uint32_t d = 0; d < D; ++d) t += (double)Om[(size_t)r * D + d] * (double)W[(size_t)k * D + d];
+                    P[(size_t)k * M + r] = (float)t;
+                }
+        }
+        const std::vector<float> &Q = omega_kind == OMEGA_NONE ? W : P;
+        std::vector<float> norms(K);
+        double wmax2 = 0.0;
+        for (uint32_t k = 0; k < K; ++k) {
+            double t = 0.0;
+            for (uint32_t d = 0; d < L; ++d) t += (double)Q[(size_t)k * L + d] * (double)Q[(size_t)k * L + d];
+            norms[k] = (float)t;
+            wmax2 = t > wmax2 ? t : wmax2;
+            // The screening form needs ||p||^2 and 2 p.x inside f32 range; the scalar kernels do not.
+            if (!(t < 1e37)) {
+                why = "a prototype's squared norm is not finite in f32";
+                return nullptr;
+            }
+        }
+        // ||x||^2 below this: |2 x.w| <= 2 sqrt(ss wmax2) <= 1e18 and ||w||^2 + c stay far inside f32 range
+        m.ss_limit = (float)std::min(1e36, 1e36 / (4.0 * std::max(wmax2, 1e-36)));
+        m.wmax2 = (float)wmax2;
+        if (omega_kind == OMEGA_NONE) {
+            m.mode = MODE_EUCLID;
+            m.name = "mfma_euclid";
+            m.ldp = m.R1;
+            ok = bind_euclid<16>(m, img1, W, norms, cls) || bind_euclid<32>(m, img1, W, norms, cls) ||
+                 bind_euclid<64>(m, img1, W, norms, cls) || bind_euclid<128>(m, img1, W, norms, cls) ||
+                 bind_euclid<256>(m, img1, W, norms, cls);
+        } else {
+            m.mode = MODE_OMEGA;
+            m.name = "mfma_omega";
+            m.R2 = (uint32_t)pad_pow2(M, 16);
+            m.ldp = m.R2;
+            ok = bind_lowrank<256>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<128>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_lowrank<64>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<32>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega_pipe<128>(m, img1, img2, Om, P, norms, cls) || bind_omega_pipe<64>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega_pipe<32>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<16, 16>(m, img1, img2, Om, P, norms, cls) || bind_omega<32, 16>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<32, 32>(m, img1, img2, Om, P, norms, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, norms, cls);
+        }
+        // zero-padded plain rows for the exact re-measurement
+        plain.assign((size_t)K * m.ldp, 0.0f);
+        for (uint32_t k = 0; k < K; ++k) std::memcpy(&plain[(size_t)k * m.ldp], &Q[(size_t)k * L], L * sizeof(float));
+        find_duplicates(Q, K, L, dup_first, dup_next);
+    } else {
+        m.mode = MODE_LOCAL;
+        m.name = "mfma_local";
+        std::vector<float> negp((size_t)K * M);                        // -Omega_j w_j (f64, rounded once)
+        for (uint32_t j = 0; j < K; ++j)
+            for (uint32_t r = 0; r < M; ++r) {
+                double t = 0.0;
+                for (uint32_t d = 0; d < D; ++d)
+                    t += (double)Om[((size_t)j * M + r) * D + d] * (double)W[(size_t)j * D + d];
+                negp[(size_t)j * M + r] = (float)(-t);
+            }
+        ok = bind_local<16>(m, img1, Om, negp, cls) || bind_local<32>(m, img1, Om, negp, cls) ||
+             bind_local<64>(m, img1, Om, negp, cls) || bind_local<128>(m, img1, Om, negp, cls) ||
+             bind_local<256>(m, img1, Om, negp, cls);
+    }
+    if (!ok) {
+        why = "no engine instantiation for this (D, M) pair";
+        return nullptr;
+    }
+
+    EngineModel *out = new EngineModel(m);
+    herr = to_device(&out->img1, img1);
+    if (herr == hipSuccess && !img2.empty()) herr = to_device(&out->img2, img2);
+    if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
+    if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
+    if (herr == hipSuccess && !dup_first.empty()) herr = to_device(&out->dup_first, dup_first);
+    if (herr == hipSuccess && !dup_next.empty()) herr = to_device(&out->dup_next, dup_next);
+    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, QUEUE_SLOTS * QUEUE_STRIDE * sizeof(uint32_t));
+    if (herr != hipSuccess) {
+        engine_free(out);
+        return nullptr;
+    }
+    return out;
+}
+
+void engine_free(EngineModel *m)
+{
+    if (!m) return;
+    (void)hipFree(m->img1);
+    (void)hipFree(m->img2);
+    (void)hipFree(m->plain);
+    (void)hipFree(m->cls);
+    (void)hipFree(m->queue);
+    (void)hipFree(m->dup_first);
+    (void)hipFree(m->dup_next);
+    delete m;
+}
+
+const char *engine_name(const EngineModel *m) { return m->name; }
+
+hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s)
+{
+    if (N == 0) return hipSuccess;
+    EngineArgs a;
+    a.X = dX; a.N = N; a.D = m->D; a.y = dy;
+    a.img1 = m->img1; a.ngroups1 = m->ngroups1;
+    a.img2 = m->img2; a.ngroups2 = m->ngroups2;
+    a.plain = m->plain; a.ldp = m->ldp;
+    a.K = m->K; a.tiles_per_proto = m->tiles_per_proto;
+    a.nbatches = (N + m->samples_per_batch - 1) / m->samples_per_batch;
+    a.out = out;
+    a.ss_limit = m->ss_limit;
+    a.wmax2 = m->wmax2;
+    a.dbg = nullptr;
+    static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
+    if (variant_env() == 31) {
+        if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
+        a.dbg = dbg_buf;
+    }
+    a.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
+    a.dup_first = m->dup_first;
+    a.dup_next = m->dup_next;
+    a.cls = m->cls;
+    hipError_t e = m->launch(a, dy != nullptr, s);
+    if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch
+        (void)hipStreamSynchronize(s);
+        const size_t nw = 512 * 4;
+        std::vector<unsigned long long> h(nw * 8);
+        (void)hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        for (size_t w = 0; w < nw; ++w)
+            for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
+        double tot = 0;
+        for (int i = 0; i < 7; ++i) tot += sum[i];
+        if (variant_env() == 31) {
+            double s4[6] = {0};
+            for (size_t w = 0; w < (size_t)256 * (getenv("VQHIP_NW4") ? 4 : 8); ++w)
+                for (int i = 0; i < 6; ++i) s4[i] += (double)h[w * 8 + i];
+            unsigned long long b0 = ~0ull, b1 = 0, e0 = ~0ull, e1 = 0;
+            for (size_t w = 0; w < (size_t)256 * (getenv("VQHIP_NW4") ? 4 : 8); ++w) {
+                b0 = std::min(b0, h[w * 8 + 6]); b1 = std::max(b1, h[w * 8 + 6]);
+                e0 = std::min(e0, h[w * 8 + 7]); e1 = std::max(e1, h[w * 8 + 7]);
+            }
+            fprintf(stderr, "loop start spread %.1f us, first start -> first end %.1f us, -> last end %.1f us\n", (b1 - b0) / 100.0,
+                    (e0 - b0) / 100.0, (e1 - b0) / 100.0);
+            fprintf(stderr, "in-kernel clock %.3f GHz (span %.0f cycles = %.1f us)\n", s4[4] / s4[5] * 0.1, s4[4] / (getenv("VQHIP_NW4") ? 1024 : 2048), s4[5] / (getenv("VQHIP_NW4") ? 1024 : 2048) / 100.0);
+            const double nwv = getenv("VQHIP_NW4") ? 1024 : 2048;
+            fprintf(stderr, "pipe phase cycles per wave: image_load(10ns ticks) %.0f prefetch_issue %.0f tiles %.0f epilogue %.0f\n", s4[0] / nwv,
+                    s4[1] / nwv, s4[2] / nwv, s4[3] / nwv);
+        } else
+        fprintf(stderr, "phase cycles per wave: loads %.0f dma %.0f mma %.0f tile_epi %.0f barrier %.0f batch_epi %.0f tail %.0f total %.0f\n",
+                sum[0] / nw, sum[1] / nw, sum[2] / nw, sum[3] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, tot / nw);
+    }
+    return e;
+}
+
+}  // namespace vq

@@ -1,0 +1,396 @@
+// MFMA tile engine for gfx950: nearest-prototype search as streamed-weight f32 MFMA GEMMs.
+// Geometry and the reasons behind it: engine.h.  What each kernel restates:
+//
+//   k_engine<MODE_EUCLID>  find_closest_prototype{,_matched}, omega = None     src/helpers.rs:55-77, 91-132
+//        screening score_k = ||w_k||^2 - 2 x.w_k on the matrix cores (argmin-equivalent to
+//        helpers.rs:11-24), best TWO candidates per sample re-measured in the direct
+//        sum (x_d - w_kd)^2 form, rooted, compared like helpers.rs:70.
+//   k_engine<MODE_OMEGA>   the same with Some(omega): y = Omega x on the matrix cores, then the
+//        Euclidean machinery in the projected space against p_k = Omega w_k; distance
+//        ||y - p_k||^2 = (x-w)^T Omega^T Omega (x-w), squared                  src/helpers.rs:35-45
+//   k_engine<MODE_LOCAL>   LGMLVQ: z = Omega_j x - Omega_j w_j per prototype j, ||z||^2,
+//        strict '<' in index order                                             src/lgmlvq/lgmlvq.rs:436-506
+//
+// One workgroup = 4 waves; each wave keeps S tiles of 32 samples in registers and all waves walk
+// the same stream of weight-tile groups through a double-buffered LDS stage filled by LDS-DMA
+// (global_load_lds_dwordx4), one barrier per group.
+#include <cstdlib>
+
+#include "mfma_device.h"
+
+namespace vq {
+
+// ------------------------------------------------------------------------------ the kernel
+// R1: padded sample length.  R2: padded projected length (OMEGA only).  S: sample tiles per wave.
+//
+// Batches (4 waves x S tiles x 32 samples) are claimed by the workgroup from a global counter: the two
+// workgroups of a CU do not get equal shares of the matrix pipes, so a fixed split leaves half the
+// waves of the chip running alone at the end.  Thread 0 claims the next batch at the top of a batch;
+// one barrier publishes it.  OMEGA: the samples are dead once they are
+// projected, so the next batch's rows are fetched into the same registers while the search runs
+// (every workgroup of the chip loading, then computing, in lockstep is an HBM burst followed by HBM
+// silence).  The search stages screen with packed keys (4 VALU per score, see k_resident_pipe).
+template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
+{
+    using G1 = Geom<R1>;
+    using G2 = Geom<MODE == MODE_OMEGA ? R2 : R1>;
+    constexpr int RS = MODE == MODE_OMEGA ? R2 : R1;                 // reduction length of the search stage
+    constexpr int BUF_BYTES = G1::STAGE_BYTES > G2::STAGE_BYTES ? G1::STAGE_BYTES : G2::STAGE_BYTES;
+    constexpr bool ROOT = MODE == MODE_EUCLID;                       // helpers.rs:23 vs :44
+    // OMEGA: Omega is zero padded to max(32, R2) rows, so the projection stages are known at compile time
+    constexpr int T1 = R2 >= 32 ? R2 / 32 : 1;
+    constexpr int NG1 = (T1 + G1::G - 1) / G1::G;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+    __shared__ uint32_t claimed;                                     // the batch after this one
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ngroups = MODE == MODE_OMEGA ? NG1 + a.ngroups2 : a.ngroups1;
+    const uint32_t Cact = a.D >> 2;
+
+    // DMA source of stage q of the cyclic weight stream
+    auto issue = [&](uint32_t q, int buf) {
+        char *dst = smem + buf * BUF_BYTES;
+        if (MODE == MODE_OMEGA && q >= (uint32_t)NG1)
+            stage_group<G2::STAGE_BYTES>(dst, (const char *)(a.img2 + (size_t)(q - NG1) * G2::STAGE_FLOATS), wave, lane);
+        else
+            stage_group<G1::STAGE_BYTES>(dst, (const char *)(a.img1 + (size_t)q * G1::STAGE_FLOATS), wave, lane);
+    };
+
+    // This wave's S tiles of 32 samples of batch bb -> B fragments, straight from HBM, 16 B per lane, through a
+    // buffer descriptor rebased per tile (wave-uniform): rows past N read as zeros by the hardware range
+    // check, one per-lane offset + immediates serves every chunk.  The loads are raw: nothing here waits for
+    // them, so a batch can be fetched while the previous one is searched.
+    f32x4 xf[S][R1 / 8];
+    uint32_t label[S];
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    auto load_samples = [&](uint64_t bb) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint64_t first = ((bb * 4 + wave_u) * S + s) * 32;
+            uint32_t rec = 0u, rec_y = 0u;
+            if (bb < a.nbatches && first < a.N) {
+                const uint64_t left = a.N - first;
+                rec = left * row_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * row_bytes);
+                rec_y = left * 4u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * 4u);
+            }
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + first * a.D), 0, (int)rec, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < R1 / 8; ++j)
+                xf[s][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+            if (MATCHED) {
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + first), 0, (int)rec_y, 0x00020000);
+                label[s] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+            } else {
+                label[s] = 0u;
+            }
+        }
+    };
+    // D < R1: the chunks past the row's end hold the next row's values (or range-check zeros); the weight
+    // images are zero there, but 0 x INF is NaN, so they are cleared before the rows are used
+    auto mask_columns = [&]() {
+        if (Cact < (uint32_t)(R1 / 4)) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int j = 0; j < R1 / 8; ++j)
+                    if ((uint32_t)(2 * j + h) >= Cact) xf[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    int cur = 0;
+    uint64_t b = blockIdx.x;
+    if (b < a.nbatches) {
+        issue(0, 0);
+        load_samples(b);
+        __syncthreads();                                             // waits vmcnt(0) for the DMA, then barrier
+    }
+
+    // thread 0 keeps one claim in flight: the atomic issued at the top of batch k returns batch k + 2
+    uint32_t pending = 0u;
+    if (tid == 0) pending = gridDim.x + atomicAdd(a.queue, 1u);
+
+    while (b < a.nbatches) {
+        if (tid == 0) {
+            claimed = pending;                                       // the wait for the atomic of a batch ago is here
+            pending = gridDim.x + atomicAdd(a.queue, 1u);
+        }
+        __syncthreads();
+        const uint64_t bnext = claimed;
+        mask_columns();
+        uint64_t sample[S];
+        uint32_t lab[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sample[s] = ((b * 4 + wave) * S + s) * 32 + s_col;
+            lab[s] = label[s];
+        }
+
+        f32x4 yf[S][RS / 8];                                          // search-stage fragments
+        Keys2 ku[S];
+        KeysM km[S];
+        Best1 pos[S], neg[S];                                         // LOCAL: exact distances, offered in index order
+        float dsum[S];
+        bool unsafe[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            dsum[s] = 0.0f;
+            unsafe[s] = false;
+        }
+        if (MODE != MODE_OMEGA) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int j = 0; j < RS / 8; ++j) yf[s][j] = xf[s][j < R1 / 8 ? j : 0];
+        } else {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int j = 0; j < RS / 8; ++j) yf[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+        // One step of the cyclic weight stream: prefetch the next stage, compute on this one, barrier.
+        uint32_t q = 0;
+        auto step = [&](auto &&compute) {
+            const bool wrap = q + 1 == ngroups;
+            if (!(wrap && bnext >= a.nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);   // nothing to stage after the last batch
+            if (MODE == MODE_OMEGA && q == (uint32_t)NG1) {
+                // x is dead: the next batch's rows are fetched now and arrive while the search runs.  vmcnt
+                // counts in issue order, so they go out AFTER this step's DMA, and this step's barrier waits
+                // for everything but them (a barrier that waited for vmcnt(0) would sit out an HBM round trip).
+                load_samples(bnext);
+                compute((const float *)(smem + cur * BUF_BYTES));
+                static_assert(S * (R1 / 8) + 1 <= 63, "vmcnt is a 6-bit counter");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(S * (R1 / 8) + (MATCHED ? S : 0)) : "memory");
+            } else {
+                compute((const float *)(smem + cur * BUF_BYTES));
+                __syncthreads();               // next stage landed (vmcnt(0)) and everyone is done reading this one
+            }
+            cur ^= 1;
+            ++q;
+        };
+
+        if constexpr (MODE == MODE_OMEGA) {
+            // ---- projection: y = Omega x; accumulator registers become the search stage's fragment:
+            //      row 8g + 4h + e of Omega tile t  ==  element e of chunk 2(4t + g) + h of y
+            static_for<0, NG1>([&](auto q1) {
+                step([&](const float *stage) {
+                    static_for<0, G1::G>([&](auto tt) {
+                        constexpr int t = decltype(q1)::value * G1::G + decltype(tt)::value;
+                        f32x16 acc[S];
+                        tile_mma<R1, S>(stage + decltype(tt)::value * G1::TILE_FLOATS, xf, acc, s_col, h);
+                        static_for<0, 4>([&](auto g) {
+                            constexpr int jj = 4 * t + decltype(g)::value;
+                            if constexpr (jj < RS / 8) {
+#pragma unroll
+                                for (int s = 0; s < S; ++s)
+                                    yf[s][jj] = f32x4{acc[s][4 * g], acc[s][4 * g + 1], acc[s][4 * g + 2], acc[s][4 * g + 3]};
+                            }
+                        });
+                    });
+                });
+            });
+        }
+
+        if constexpr (MODE != MODE_LOCAL) {
+            // samples whose screening scores could leave the f32 range go to the exact scan
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float ss = 0.0f;
+#pragma unroll
+                for (int j = 0; j < RS / 8; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ss = fmaf(yf[s][j][e], yf[s][j][e], ss);
+                ss += xor32(ss);
+                unsafe[s] = !(ss < a.ss_limit);
+            }
+        }
+
+        const uint32_t nsearch = MODE == MODE_OMEGA ? a.ngroups2 : a.ngroups1;
+        for (uint32_t qs = 0; qs < nsearch; ++qs) {
+            step([&](const float *stage) {
+                if constexpr (MODE == MODE_LOCAL) {
+                    // ---- z = Omega_j x - Omega_j w_j (accumulator starts at -p_j), ||z||^2 summed per prototype
+#pragma unroll
+                    for (int tt = 0; tt < G1::G; ++tt) {
+                        const float *tile = stage + tt * G1::TILE_FLOATS;
+                        f32x16 acc[S];
+                        tile_mma<R1, S>(tile, xf, acc, s_col, h);
+                        const uint32_t ti = qs * G1::G + tt;
+                        const uint32_t j = ti / a.tiles_per_proto, t = ti % a.tiles_per_proto;
+#pragma unroll
+                        for (int s = 0; s < S; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) dsum[s] = fmaf(acc[s][r], acc[s][r], dsum[s]);
+                        if (t + 1 == a.tiles_per_proto) {
+                            const uint32_t cj = ((const uint32_t *)(tile + G1::W_FLOATS))[32];
+#pragma unroll
+                            for (int s = 0; s < S; ++s) {
+                                const float total = dsum[s] + xor32(dsum[s]);
+                                dsum[s] = 0.0f;
+                                if (j < a.K) {                        // pad tiles past the last prototype never compete
+                                    if (!MATCHED || cj == lab[s]) pos[s].offer(total, j);   // lgmlvq.rs:448 / :487
+                                    else neg[s].offer(total, j);                             // lgmlvq.rs:496
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // ---- search stage: key of ||p_k||^2 + c - 2 y.p_k for 32 prototypes per tile
+#pragma unroll
+                    for (int tt = 0; tt < G2::G; ++tt) {
+                        const float *tile = stage + tt * G2::TILE_FLOATS;
+                        f32x16 acc[S];
+                        tile_mma<RS, S>(tile, yf, acc, s_col, h);
+                        const uint32_t tile_id = qs * G2::G + tt;
+                        const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32 + 4 * h;
+                        Keys2 ou[S];
+                        KeysM om[S];
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            ou[s] = ku[s];
+                            om[s] = km[s];
+                        }
+                        if constexpr (!MATCHED) {
+#pragma unroll
+                            for (int s = 0; s < S; ++s) {
+                                screen16<1>(acc[s], ku[s]);            // acc[s] is fresh from the matrix pipe
+                                settle_tiles(ku[s], ou[s], tile_id);
+                            }
+                        } else {
+                            static_for<0, 16>([&](auto oo) {
+                                constexpr int o = decltype(oo)::value;
+                                const uint32_t cls = tcls[8 * (o >> 2) + (o & 3)];
+#pragma unroll
+                                for (int s = 0; s < S; ++s) {
+                                    const uint32_t key = pack_key(acc[s][o], o);
+                                    const bool match = cls == lab[s];                 // helpers.rs:113 / :122
+                                    const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
+                                    km[s].p = kmin(km[s].p, kp);
+                                    km[s].n = kmin(km[s].n, kn);
+                                }
+                            });
+#pragma unroll
+                            for (int s = 0; s < S; ++s) {
+                                km[s].tp = km[s].p != om[s].p ? tile_id : om[s].tp;
+                                km[s].tn = km[s].n != om[s].n ? tile_id : om[s].tn;
+                            }
+                        }
+                    }
+                }
+            });
+        }
+
+        // ---- epilogue: lane pair (s, h=0/1) agrees on the candidates, re-measures them exactly, stores
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool live = sample[s] < a.N;
+            Best1 wp, wn;                                              // final (distance, index)
+            if (MODE == MODE_LOCAL) {
+                wp = pos[s];
+                wn = neg[s];
+            } else {
+                bool rescan = unsafe[s];
+                auto measure = [&](uint32_t k) {
+                    const float d = exact_sq<RS>(yf[s], a.plain, a.ldp, k, h);
+                    return ROOT ? sqrtf(d) : d;
+                };
+                if (!MATCHED) {
+                    const uint32_t k1 = key_row(ku[s].b1, ku[s].t1, h), k2 = key_row(ku[s].b2, ku[s].t2, h);
+                    const uint32_t pb1 = xor32(ku[s].b1), pb2 = xor32(ku[s].b2), pk1 = xor32(k1), pk2 = xor32(k2);
+                    uint32_t f, fi, sd, si;                            // best two of the pair's four, by (key, index)
+                    if (keyless(pb1, pk1, ku[s].b1, k1)) {
+                        f = pb1; fi = pk1;
+                        if (keyless(ku[s].b1, k1, pb2, pk2)) { sd = ku[s].b1; si = k1; } else { sd = pb2; si = pk2; }
+                    } else {
+                        f = ku[s].b1; fi = k1;
+                        if (keyless(pb1, pk1, ku[s].b2, k2)) { sd = pb1; si = pk1; } else { sd = ku[s].b2; si = k2; }
+                    }
+                    if (key_valid(f) && !rescan) {
+                        const float d1 = measure(fi);
+                        wp.d = d1; wp.i = fi;
+                        if (key_valid(sd)) {
+                            const float d2 = measure(si);
+                            if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+                        }
+                        rescan = !(wp.d < INFINITY);
+                    } else {
+                        rescan = true;
+                    }
+                } else {
+                    uint32_t kp = key_row(km[s].p, km[s].tp, h), kn = key_row(km[s].n, km[s].tn, h), p = km[s].p, n = km[s].n;
+                    const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
+                    if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
+                    if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
+                    if (key_valid(p)) {
+                        wp.d = measure(kp); wp.i = kp;
+                        rescan |= !(wp.d < INFINITY);
+                    }
+                    if (key_valid(n)) {
+                        wn.d = measure(kn); wn.i = kn;
+                        rescan |= !(wn.d < INFINITY);
+                    }
+                }
+                if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn);
+                settle_ties<MATCHED>(a, lab[s], wp, wn);
+            }
+            if (live) {
+                if (h == 0) {
+                    if (a.out.idx) a.out.idx[sample[s]] = wp.i;
+                    if (MATCHED && a.out.jneg) a.out.jneg[sample[s]] = wn.i;
+                } else {
+                    if (a.out.dist) a.out.dist[sample[s]] = wp.d;
+                    if (MATCHED && a.out.dneg) a.out.dneg[sample[s]] = wn.d;
+                }
+            }
+        }
+        if (MODE != MODE_OMEGA) load_samples(bnext);
+        b = bnext;
+    }
+}
+
+namespace {
+// WPS = workgroups per CU = waves per SIMD the register budget is cut for (256-thread workgroups).
+template <int MODE, int R1, int R2, int S, int WPS = (R1 >= 256 ? 1 : 2)>
+hipError_t launch_t(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t cap = 256ull * WPS;                                // 256 CUs x workgroups per CU
+    const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false, WPS>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int MODE, int R1, int R2, int S>
+bool pick(int mode, int r1, int r2, LaunchFn &fn, int *samples_per_batch)
+{
+    if (mode != MODE || r1 != R1 || (MODE == MODE_OMEGA && r2 != R2)) return false;
+    fn = &launch_t<MODE, R1, R2, S>;
+    *samples_per_batch = 4 * S * 32;                                  // 4 waves x S tiles x 32 samples
+    return true;
+}
+}  // namespace
+
+LaunchFn streamed_launcher(int mode, int R1, int R2, int *spb)
+{
+    LaunchFn fn = nullptr;
+    (void)(pick<MODE_EUCLID, 16, 16, 2>(mode, R1, R2, fn, spb) || pick<MODE_EUCLID, 32, 32, 2>(mode, R1, R2, fn, spb) ||
+           pick<MODE_EUCLID, 64, 64, 2>(mode, R1, R2, fn, spb) || pick<MODE_EUCLID, 128, 128, 1>(mode, R1, R2, fn, spb) ||
+           pick<MODE_EUCLID, 256, 256, 1>(mode, R1, R2, fn, spb) ||
+           pick<MODE_OMEGA, 128, 128, 1>(mode, R1, R2, fn, spb) || pick<MODE_OMEGA, 256, 16, 1>(mode, R1, R2, fn, spb) ||
+           pick<MODE_OMEGA, 16, 16, 1>(mode, R1, R2, fn, spb) || pick<MODE_OMEGA, 32, 16, 1>(mode, R1, R2, fn, spb) ||
+           pick<MODE_OMEGA, 32, 32, 1>(mode, R1, R2, fn, spb) || pick<MODE_OMEGA, 64, 64, 1>(mode, R1, R2, fn, spb) ||
+           pick<MODE_LOCAL, 16, 16, 2>(mode, R1, R2, fn, spb) || pick<MODE_LOCAL, 32, 32, 2>(mode, R1, R2, fn, spb) ||
+           pick<MODE_LOCAL, 64, 64, 2>(mode, R1, R2, fn, spb) || pick<MODE_LOCAL, 128, 128, 2>(mode, R1, R2, fn, spb) ||
+           pick<MODE_LOCAL, 256, 256, 1>(mode, R1, R2, fn, spb));
+    return fn;
+}
+
+}  // namespace vq

@@ -1,0 +1,445 @@
+// LDS-resident kernels for the Omega models on gfx950 (GMLVQ / LiRaMLVQ predict and matched search:
+// src/helpers.rs:35-45 through 55-77, 91-132): k_lowrank_pipe (Omega with at most 16 rows, Omega and the projected
+// prototypes resident) and k_omega_pipe (Omega about square, projected prototypes resident, Omega from L2).
+#include <cstdlib>
+
+#include "mfma_device.h"
+
+namespace vq {
+
+// ------------------------------------------------------------------------------ resident low-rank Omega kernel
+// LiRaMLVQ-shaped models (Omega with at most 16 rows, src/liramlvq/liramlvq.rs:287-307 through
+// helpers.rs:35-45): Omega AND the projected prototypes p_k = Omega w_k stay in LDS for the whole
+// launch (config 4: 16.3 + 88 KiB), so a wave never meets a barrier after the image load.
+//   * projection y = Omega x on v_mfma_f32_16x16x4_f32: 16 Omega rows on the M axis (a 32-row MFMA
+//     would spend half of its rows on padding), 2 groups of 16 samples on the N axis, the 4 lane
+//     groups share out the reduction index.  x is consumed straight out of the registers the loads
+//     of the previous batch filled, and the next batch's loads go out as soon as it is projected.
+//   * one lane <-> lane^16 exchange turns the 16x16 accumulators into the B fragment of the 32x32x2
+//     search stage; lane half h then holds y[8h .. 8h+7], so the prototype image is built with
+//     chunks 1 and 2 of every row swapped (image chunk 2j+h <- chunk 2h+j of p_k).
+//   * the search is k_resident_pipe's (half_step / packed keys / exact re-measurement) at R = 16,
+//     distance squared and not rooted (helpers.rs:44).
+template <int R1, bool MATCHED, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineArgs a)
+{
+    using Gs = Geom<16>;
+    constexpr int ROWF = R1 + 4;                       // Omega row stride in LDS: rows start 4 banks apart
+    constexpr int NJ = R1 / 16;                        // projection steps: 4 MFMAs per step and sample group
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const int n16 = lane & 15, kg = lane >> 4;
+    const uint32_t ntiles = a.ngroups2 * Gs::G;       // even (G = 8)
+    const uint32_t p_bytes = ntiles * Gs::TILE_BYTES;
+
+    {   // both images -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        auto to_lds = [&](uint32_t dst, const char *src, uint32_t bytes) {
+            for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+                const uint32_t off = p * 1024u + lane * 16u;
+                if (off < bytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                     (__attribute__((address_space(3))) void *)(smem + dst + p * 1024u), 16, 0, 0);
+            }
+        };
+        to_lds(0u, (const char *)a.img2, p_bytes);
+        to_lds(p_bytes, (const char *)a.img1, 16u * ROWF * 4u);
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+    const float *om = (const float *)(smem + p_bytes) + n16 * ROWF + kg * 4;   // this lane's Omega row and k group
+
+    // batch queue: as in k_resident_pipe
+    constexpr uint32_t BLOCK = 2;
+    uint32_t pending = 0u;
+    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    auto request = [&]() {
+        uint32_t fresh;
+        if (lane == 0)
+            fresh = __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    };
+#pragma clang diagnostic pop
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    uint32_t in_block = 0;
+    request();
+    auto successor = [&](uint64_t &nb0, uint32_t &nin) {
+        if (in_block + 1 < BLOCK) {
+            nb0 = block0;
+            nin = in_block + 1;
+        } else {
+            uint32_t p = pending;
+            asm volatile("" : "+v"(p));
+            nb0 = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);   // added here: a VALU use next to the atomic would wait for it there
+            nin = 0;
+        }
+    };
+    // lane (n16, kg) loads 16 B of row n16 (group 0) and row 16 + n16 (group 1) per step: chunk 4j + kg
+    constexpr uint32_t row_bytes = R1 * 4u;
+    const uint32_t voff0 = (uint32_t)n16 * row_bytes + (uint32_t)kg * 16u;
+    const uint32_t voff1 = voff0 + 16u * row_bytes;
+    f32x4 xn[2][NJ];
+    uint32_t ln = 0u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    auto fetch = [&](uint64_t bb) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R1), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            xn[0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff0 + j * 64, 0, 0));
+            xn[1][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff1 + j * 64, 0, 0));
+        }
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    uint64_t b = block0;
+    fetch(b);
+
+    while (b < a.nbatches) {
+        uint64_t nb0;
+        uint32_t nin;
+        successor(nb0, nin);
+        const uint64_t bnext = nb0 + nin;
+
+        // ---- projection: accA / accB = y of samples n16 / 16 + n16, rows 4 kg .. 4 kg + 3
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+        {
+            f32x4 anext = *(const f32x4 *)om;
+            static_for<0, NJ>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                const f32x4 acur = anext;
+                if constexpr (j + 1 < NJ) anext = *(const f32x4 *)(om + 16 * (j + 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[e], xn[0][j][e], accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[e], xn[1][j][e], accB, 0, 0, 0);
+                }
+            });
+        }
+        const uint32_t label = ln;
+        // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
+        // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
+        asm volatile("" ::: "memory");
+        if (nin == 0) request();
+        fetch(bnext);
+
+        // ---- 16x16 accumulators -> B fragment of the 32x32x2 search: lane (s, h) gets y[8h .. 8h+7] of sample s
+        f32x4 yf[2];
+        {
+            const bool up = (lane & 16) != 0;          // this lane's sample sits in group 1
+            f32x4 own, recv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                own[r] = up ? accB[r] : accA[r];
+                const float send = up ? accA[r] : accB[r];
+                recv[r] = __shfl_xor(send, 16, 64);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                yf[0][r] = up ? recv[r] : own[r];
+                yf[1][r] = up ? own[r] : recv[r];
+            }
+        }
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
+        ss += xor32(ss);                               // ||y||^2, the same value in both lanes of the pair
+        const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge: exact scan at the end
+        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+
+        // ---- search in the projected space (k_resident_pipe's tile loop at R = 16)
+        Keys2 ku;
+        KeysM km;
+        f32x16 acc0, acc1;
+        f32x4 a0 = *(const f32x4 *)(img + Gs::chunk_off(s_col, h));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
+            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;
+        const float *tprev = img;
+        uint32_t tid = 0;
+        for (uint32_t t = 0; t < ntiles; t += 2) {
+            const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
+            const float *tile1 = tile + Gs::TILE_FLOATS;
+            const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
+            half_step<16, MATCHED>(tile, tile1, tprev, tid, label, yf, acc0, acc1, a0, s_col, h, ku, km);
+            half_step<16, MATCHED>(tile1, next, tile, t, label, yf, acc1, acc0, a0, s_col, h, ku, km);
+            tprev = tile1;
+            tid = t + 1;
+        }
+        last_screen<16, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+
+        Best1 wp, wn;
+        finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+        settle_ties<MATCHED>(a, label, wp, wn);
+        {
+            const int rec = (int)records(b, 4u);
+            const uint32_t so = (uint32_t)s_col * 4u;
+            auto put = [&](void *base, uint32_t bits) {
+                __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+            };
+            if (h == 0) {
+                if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+            } else {
+                if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+            }
+        }
+        b = bnext;
+        block0 = nb0;
+        in_block = nin;
+    }
+}
+
+// ------------------------------------------------------------------------------ resident-prototype Omega kernel
+// GMLVQ-shaped models (Omega with about as many rows as columns, src/gmlvq/gmlvq.rs:270-290 through
+// helpers.rs:35-45): the projected prototypes p_k = Omega w_k stay in LDS for the whole launch as in
+// k_resident_pipe (config 3: 134 KiB), which leaves no room for Omega (66 KiB).  Omega's A fragments
+// come straight from L2 instead: the host lays Omega out as one 1 KiB piece per (tile, reduction step)
+// -- 16 bytes per lane, exactly the fragment -- and every wave keeps a ring of DEPTH pieces in flight
+// ahead of its MFMAs.  No LDS stage, no barrier after the image load: waves run independently and
+// claim batches from the queue.  The projection's accumulators are the search stage's B fragment
+// (engine.h), the search is k_resident_pipe's, distance squared and not rooted (helpers.rs:44).
+template <int R, bool MATCHED, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs a)
+{
+    using Gs = Geom<R>;
+    constexpr int NT = R / 32, NJ = R / 8, NSTEP = NT * NJ;   // Omega tiles, reduction steps per tile, pieces
+    constexpr int DEPTH = 6;                                  // Omega pieces in flight per wave
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = a.ngroups2 * Gs::G;       // even (host pads)
+
+    {   // prototype image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        const uint32_t bytes = ntiles * Gs::TILE_BYTES;
+        const char *src = (const char *)a.img2;
+        for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+    // Omega pieces: piece i = (tile i / NJ, step i % NJ), this lane's 16 bytes at i * 1024 + lane * 16
+    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, NSTEP * 1024, 0x00020000);
+    const uint32_t om_off = (uint32_t)lane * 16u;
+    auto piece = [&](int i) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, i * 1024, 0));
+    };
+
+    // batch queue: as in k_resident_pipe
+    constexpr uint32_t BLOCK = 2;
+    uint32_t pending = 0u;
+    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    auto request = [&]() {
+        uint32_t fresh;
+        if (lane == 0)
+            fresh = __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    };
+#pragma clang diagnostic pop
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    uint32_t in_block = 0;
+    request();
+    auto successor = [&](uint64_t &nb0, uint32_t &nin) {
+        if (in_block + 1 < BLOCK) {
+            nb0 = block0;
+            nin = in_block + 1;
+        } else {
+            uint32_t p = pending;
+            asm volatile("" : "+v"(p));
+            nb0 = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);   // added here: a VALU use next to the atomic would wait for it there
+            nin = 0;
+        }
+    };
+    const uint32_t row_bytes = R * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    f32x4 xn[R / 8];                                   // rows of the next batch, in flight
+    uint32_t ln = 0u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    auto fetch = [&](uint64_t bb) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j)
+            xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    uint64_t b = block0;
+    fetch(b);
+
+    while (b < a.nbatches) {
+        uint64_t nb0;
+        uint32_t nin;
+        successor(nb0, nin);
+        const uint64_t bnext = nb0 + nin;
+
+        // ---- projection y = Omega x: 32 Omega rows per tile, A fragments from the ring; the accumulators of
+        //      tile t are chunks 2(4t + g) + h of y, i.e. fragment entries 4t + g of the search stage
+        f32x4 yf[R / 8];
+        {
+            f32x4 ring[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = piece(i);
+            static_for<0, NT>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                static_for<0, NJ>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value, i = t * NJ + j;
+                    const f32x4 av = ring[i % DEPTH];
+                    if constexpr (i + DEPTH < NSTEP) ring[i % DEPTH] = piece(i + DEPTH);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xn[j][e], acc, 0, 0, 0);
+                });
+#pragma unroll
+                for (int g = 0; g < 4; ++g) yf[4 * t + g] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+            });
+        }
+        const uint32_t label = ln;
+        // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
+        // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
+        asm volatile("" ::: "memory");
+        if (nin == 0) request();
+        fetch(bnext);
+
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
+        ss += xor32(ss);                               // ||y||^2, the same value in both lanes of the pair
+        const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge: exact scan at the end
+        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+
+        // ---- search in the projected space (k_resident_pipe's tile loop)
+        Keys2 ku;
+        KeysM km;
+        f32x16 acc0, acc1;
+        f32x4 a0 = *(const f32x4 *)(img + Gs::chunk_off(s_col, h));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
+            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;
+        const float *tprev = img;
+        uint32_t tid = 0;
+        for (uint32_t t = 0; t < ntiles; t += 2) {
+            const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
+            const float *tile1 = tile + Gs::TILE_FLOATS;
+            const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
+            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, yf, acc0, acc1, a0, s_col, h, ku, km);
+            half_step<R, MATCHED>(tile1, next, tile, t, label, yf, acc1, acc0, a0, s_col, h, ku, km);
+            tprev = tile1;
+            tid = t + 1;
+        }
+        last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+
+        Best1 wp, wn;
+        finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+        settle_ties<MATCHED>(a, label, wp, wn);
+        {
+            const int rec = (int)records(b, 4u);
+            const uint32_t so = (uint32_t)s_col * 4u;
+            auto put = [&](void *base, uint32_t bits) {
+                __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+            };
+            if (h == 0) {
+                if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+            } else {
+                if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+            }
+        }
+        b = bnext;
+        block0 = nb0;
+        in_block = nin;
+    }
+}
+
+namespace {
+template <int R1>
+hipError_t launch_lowrank(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_lowrank_pipe<R1, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_lowrank_pipe<R1, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int R>
+hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_omega_pipe<R, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_omega_pipe<R, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn lowrank_launcher(int R1)
+{
+    switch (R1) {
+    case 32: return &launch_lowrank<32>;
+    case 64: return &launch_lowrank<64>;
+    case 128: return &launch_lowrank<128>;
+    case 256: return &launch_lowrank<256>;
+    default: return nullptr;
+    }
+}
+
+LaunchFn omega_pipe_launcher(int R)
+{
+    switch (R) {
+    case 32: return &launch_omega_pipe<32>;
+    case 64: return &launch_omega_pipe<64>;
+    case 128: return &launch_omega_pipe<128>;
+    default: return nullptr;
+    }
+}
+
+}  // namespace vq

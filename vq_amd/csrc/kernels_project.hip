@@ -1,0 +1,224 @@
+// project / project_omega on the matrix cores: src/gmlvq/gmlvq.rs:354-372,
+// src/liramlvq/liramlvq.rs:401-446.  Kernel and its host-side model (tile image of Omega or Lambda in LDS).
+#include <algorithm>
+#include <cstdlib>
+
+#include "mfma_device.h"
+#include "mfma_images.h"
+
+namespace vq {
+
+// ------------------------------------------------------------------------------ projection kernel
+// Y = X . A^T for a matrix A with `ntiles` tiles of 32 rows resident in LDS: A = Omega for project_omega
+// (src/liramlvq/liramlvq.rs:429-446), A = Lambda = Omega^T Omega for project (src/gmlvq/gmlvq.rs:354-372,
+// src/liramlvq/liramlvq.rs:401-419: the reference builds Lambda once and multiplies every sample by it).
+// The projection stage of the search kernels with a store behind it: a wave owns 32 samples per batch,
+// rows prefetched a batch ahead, lane (s, h) of a tile's accumulator holds Y[s][32 t + 8 g + 4 h .. + 3],
+// stored as 16 bytes (the lane pair writes 32 adjacent bytes, the 4 groups of a tile a whole 128-byte line
+// per sample).  Columns at or past out_dim and rows past N are not written (predicate / buffer range check).
+struct ProjectArgs {
+    const float *X;
+    uint64_t N;
+    const float *img;         // ntiles tiles of Geom<R>
+    uint32_t ntiles;
+    float *Y;                 // N x ldy
+    uint32_t ldy, col0, out_dim;   // this launch writes columns [col0, min(col0 + 32 ntiles, out_dim))
+    uint64_t nbatches;
+    uint32_t *queue;
+};
+
+template <int R, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a)
+{
+    using Gm = Geom<R>;
+    // Register sets of 32 rows each.  R <= 128: two, worked alternately -- the loads that refill a set go
+    // out right behind its last MFMA and have the other set's whole batch to land, with no copies between
+    // sets.  R = 256: one set is all the register file holds at two waves per SIMD; the partner wave of
+    // the SIMD covers the wait.
+    constexpr int SETS = R <= 128 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    {
+        const uint32_t bytes = a.ntiles * Gm::TILE_BYTES;
+        const char *src = (const char *)a.img;
+        for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+
+    // blocks of SETS batches: a wave's first block is fixed, the others are claimed from the queue one
+    // block ahead of use (the returning atomic is issued a block before its value is needed)
+    uint32_t pending = 0u;
+    const uint32_t first_dynamic = gridDim.x * NW * SETS;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    auto request = [&]() {
+        uint32_t fresh;                                // deliberately undefined off lane 0 (see k_resident_pipe)
+        if (lane == 0)
+            fresh = __hip_atomic_fetch_add(a.queue, (uint32_t)SETS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    };
+#pragma clang diagnostic pop
+    uint64_t blk = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * SETS;
+    request();
+
+    const uint32_t row_bytes = R * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    f32x4 x[SETS][R / 8];
+    auto fetch = [&](f32x4 (&xs)[R / 8], uint64_t bb) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R), 0, (int)records(bb, row_bytes), 0x00020000);
+        // issue order = use order: vmcnt counts in order, and a set's first chunk must not wait for the
+        // loads issued behind it (its own later chunks, the other set's refill)
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j) {
+            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < SETS; ++q) fetch(x[q], blk + q);
+    const uint32_t ybytes = a.ldy * 4u;
+    const uint32_t yoff = (uint32_t)s_col * ybytes;
+
+    // all tiles of one batch: Y[b*32 + s][col0 + 32 t + 8 g + 4 h .. + 3] = accumulator group g of tile t
+    auto project_batch = [&](const f32x4 (&xs)[R / 8], uint64_t bb, bool claim) {
+        const __amdgpu_buffer_rsrc_t ry =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.Y + bb * 32 * a.ldy), 0, (int)records(bb, ybytes), 0x00020000);
+        for (uint32_t t = 0; t < a.ntiles; ++t) {
+            const float *rowp = img + (size_t)t * Gm::TILE_FLOATS + Gm::chunk_off(s_col, h);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            f32x4 anext = *(const f32x4 *)rowp;
+            static_for<0, R / 8>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+                const f32x4 acur = anext;
+                if constexpr (j + 1 < R / 8) anext = *(const f32x4 *)(rowp + 8 * (j + 1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[e], xs[j][e], acc, 0, 0, 0);
+            });
+            // the claim for the block after next goes out once this block's rows have been waited for
+            if (claim && t == 0) {
+                asm volatile("" ::: "memory");
+                request();
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const uint32_t col = a.col0 + 32u * t + 8u * g + 4u * h;
+                if (col < a.out_dim) {
+                    const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, yoff + col * 4u, 0, 0);
+                }
+            }
+        }
+    };
+
+    while (blk < a.nbatches) {
+        uint32_t p = pending;
+        asm volatile("" : "+v"(p));                    // keeps the broadcast (and the wait for the atomic) here
+        const uint64_t nblk = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+        static_for<0, SETS>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            project_batch(x[q], blk + q, q == 0);
+            asm volatile("" ::: "memory");
+            fetch(x[q], nblk + q);                     // this set is free: refill it for the next block
+        });
+        blk = nblk;
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+struct ProjectModel {
+    uint32_t rows = 0, D = 0, R = 0, ntiles = 0, tile_floats = 0, tiles_per_launch = 0;
+    float *img = nullptr;
+    uint32_t *queue = nullptr;                       // QUEUE_SLOTS counters, as in EngineModel
+    mutable uint32_t next_slot = 0;
+    hipError_t (*launch)(const ProjectArgs &, hipStream_t) = nullptr;
+};
+
+namespace {
+template <int R>
+hipError_t launch_project_t(const ProjectArgs &a, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_project<R>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int R>
+bool bind_project(ProjectModel &m, std::vector<float> &img, const std::vector<float> &A)
+{
+    if (m.D != (uint32_t)R) return false;
+    uint32_t ngroups = 0;
+    img = build_images<R>(A.data(), m.rows, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, ngroups);
+    m.R = R;
+    m.ntiles = (m.rows + 31) / 32;
+    m.tile_floats = Geom<R>::TILE_FLOATS;
+    m.tiles_per_launch = (uint32_t)(RES_BYTES / Geom<R>::TILE_BYTES);
+    m.launch = &launch_project_t<R>;
+    return true;
+}
+}  // namespace
+
+ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t D, hipError_t &herr)
+{
+    herr = hipSuccess;
+    ProjectModel m;
+    m.rows = rows;
+    m.D = D;
+    std::vector<float> img;
+    if (!(bind_project<32>(m, img, A) || bind_project<64>(m, img, A) || bind_project<128>(m, img, A) || bind_project<256>(m, img, A)))
+        return nullptr;
+    ProjectModel *out = new ProjectModel(m);
+    herr = to_device(&out->img, img);
+    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, QUEUE_SLOTS * QUEUE_STRIDE * sizeof(uint32_t));
+    if (herr != hipSuccess) {
+        project_free(out);
+        return nullptr;
+    }
+    return out;
+}
+
+void project_free(ProjectModel *m)
+{
+    if (!m) return;
+    (void)hipFree(m->img);
+    (void)hipFree(m->queue);
+    delete m;
+}
+
+// dY: N x ldy, 16-byte aligned, ldy % 4 == 0 (the caller checks); column blocks of tiles_per_launch tiles
+hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float *dY, uint32_t ldy, hipStream_t s)
+{
+    if (N == 0) return hipSuccess;
+    for (uint32_t t0 = 0; t0 < m->ntiles; t0 += m->tiles_per_launch) {
+        ProjectArgs a;
+        a.X = dX; a.N = N;
+        a.img = m->img + (size_t)t0 * m->tile_floats;
+        a.ntiles = std::min(m->tiles_per_launch, m->ntiles - t0);
+        a.Y = dY; a.ldy = ldy; a.col0 = t0 * 32u; a.out_dim = m->rows;
+        a.nbatches = (N + 31) / 32;
+        a.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
+        const hipError_t e = m->launch(a, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace vq

@@ -1,0 +1,375 @@
+// LDS-resident Euclidean kernels for gfx950 (VQ / LVQ / GLVQ: src/helpers.rs:11-24, 55-77, 91-132): the whole
+// prototype image is staged in LDS once per workgroup, then every wave runs on its own -- no per-tile DMA, no
+// barriers.  k_resident_pipe (unpadded rows, the measured path of config 2) and k_resident (padded rows).
+#include <cstdlib>
+
+#include "mfma_device.h"
+
+namespace vq {
+
+// ------------------------------------------------------------------------------ resident-prototype kernel (padded rows)
+template <int R, int S, bool MATCHED>
+__global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
+{
+    using Gm = Geom<R>;
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = a.ngroups1 * Gm::G;
+    const uint32_t Cact = a.D >> 2;
+
+    {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        const uint32_t bytes = ntiles * Gm::TILE_BYTES;
+        const char *src = (const char *)a.img1;
+        for (uint32_t p = wave; p * 1024u < bytes; p += 8) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+
+    for (uint64_t b = (uint64_t)blockIdx.x * 8 + wave; b < a.nbatches; b += (uint64_t)gridDim.x * 8) {
+        f32x4 xf[S][R / 8];
+        uint64_t sample[S];
+        uint32_t label[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            sample[s] = (b * S + s) * 32 + s_col;
+            const bool live = sample[s] < a.N;
+            const float *xrow = a.X + sample[s] * a.D;
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) {
+                const uint32_t c = 2 * j + h;
+                const bool ok = live && c < Cact;
+                const f32x4 v = *(const f32x4 *)(ok ? xrow + 4 * c : a.X);
+                xf[s][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            label[s] = (MATCHED && live) ? a.y[sample[s]] : 0u;
+        }
+        Top2 top[S];
+        Best1 pos[S], neg[S];
+
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+            f32x16 acc[S];
+            tile_mma<R, S>(tile, xf, acc, s_col, h);
+            const uint32_t kbase = t * 32 + 4 * h;
+            const uint32_t *tcls = (const uint32_t *)(tile + Gm::W_FLOATS) + 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x4 cg;
+                if (MATCHED) cg = *(const u32x4 *)(tcls + 8 * g + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t k = kbase + 8 * g + e;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float v = acc[s][4 * g + e];
+                        if (!MATCHED) top[s].offer(v, k);
+                        else if (cg[e] == label[s]) pos[s].offer(v, k);           // helpers.rs:113
+                        else neg[s].offer(v, k);                                   // helpers.rs:122
+                    }
+                }
+            }
+        }
+
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool live = sample[s] < a.N;
+            Best1 wp, wn;
+            bool rescan = false;
+            if (!MATCHED) {
+                top[s].merge_halves();
+                const Top2 &t = top[s];
+                if (t.b1 < KEY_VALID_F) {
+                    const float d1 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i1, h));
+                    wp.d = d1; wp.i = t.i1;
+                    if (t.b2 < KEY_VALID_F) {
+                        const float d2 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i2, h));
+                        if (lexless(d2, t.i2, d1, t.i1)) { wp.d = d2; wp.i = t.i2; }
+                    }
+                    rescan = t.b1 == -INFINITY || !(wp.d < INFINITY);
+                }
+            } else {
+                pos[s].merge_halves();
+                neg[s].merge_halves();
+                if (pos[s].d < KEY_VALID_F) {
+                    wp.d = sqrtf(exact_sq_lds<R>(xf[s], img, pos[s].i, h)); wp.i = pos[s].i;
+                    rescan |= pos[s].d == -INFINITY || !(wp.d < INFINITY);
+                }
+                if (neg[s].d < KEY_VALID_F) {
+                    wn.d = sqrtf(exact_sq_lds<R>(xf[s], img, neg[s].i, h)); wn.i = neg[s].i;
+                    rescan |= neg[s].d == -INFINITY || !(wn.d < INFINITY);
+                }
+            }
+            if (rescan) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
+                wp = Best1();
+                wn = Best1();
+                for (uint32_t k = 0; k < a.K; ++k) {
+                    const float d = sqrtf(exact_sq_lds<R>(xf[s], img, k, h));
+                    const uint32_t ck = MATCHED ? ((const uint32_t *)(img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::W_FLOATS))[32 + (k & 31)] : 0u;
+                    if (!MATCHED || ck == label[s]) wp.offer(d, k);
+                    else wn.offer(d, k);
+                }
+            }
+            if (live) {
+                if (h == 0) {
+                    if (a.out.idx) a.out.idx[sample[s]] = wp.i;
+                    if (MATCHED && a.out.jneg) a.out.jneg[sample[s]] = wn.i;
+                } else {
+                    if (a.out.dist) a.out.dist[sample[s]] = wp.d;
+                    if (MATCHED && a.out.dneg) a.out.dneg[sample[s]] = wn.d;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ pipelined resident kernel
+// One wave = one tile of 32 samples per batch.  D == R (host checks); the image has an even number of
+// tiles (the accumulators ping-pong).  a.ss_limit: ||x||^2 below which no score can overflow.
+template <int R, bool MATCHED, bool DIAG = false, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
+{
+    using Gm = Geom<R>;
+    unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = 0;
+    auto lap = [&](int slot) {                        // diagnostic build only
+        if (DIAG) {
+            const unsigned long long t = stamp();
+            tm[slot] += t - tprev_;
+            tprev_ = t;
+        }
+    };
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const unsigned long long r_entry = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = a.ngroups1 * Gm::G;       // even (host pads)
+
+    {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        const uint32_t bytes = ntiles * Gm::TILE_BYTES;
+        const char *src = (const char *)a.img1;
+        for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+    unsigned long long t_begin = 0, r_begin = 0;
+    if (DIAG) {
+        tprev_ = t_begin = stamp();
+        r_begin = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // Batches are claimed, BLOCK at a time, by each wave from one global counter (zeroed before the
+    // launch).  Static ownership fails twice here: the older wave of a SIMD wins the arbitration for the
+    // matrix pipe, so equal shares leave the younger one alone with a quarter of its batches after its
+    // partner has exited; and when another kernel (the RCCL gather of the previous chunk) holds some CUs
+    // at launch, the workgroups that start late would still own a full share.  The returning atomic for
+    // the next block is issued two batches before its value is needed.
+    constexpr uint32_t BLOCK = 2;
+    uint32_t pending = 0u;                             // lane 0: first batch of the next block (in flight)
+    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;     // every wave's first block is fixed
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    auto request = [&]() {
+        uint32_t fresh;                                // deliberately undefined off lane 0: no merge copy, so the
+        if (lane == 0)                                 // compiler's wait for the atomic lands at the first use
+            fresh = __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    };
+#pragma clang diagnostic pop
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    uint32_t in_block = 0;                             // position of b inside the current block
+    request();
+    // the batch after (block0, in_block)
+    auto successor = [&](uint64_t &nb0, uint32_t &nin) {
+        if (in_block + 1 < BLOCK) {
+            nb0 = block0;
+            nin = in_block + 1;
+        } else {
+            uint32_t p = pending;
+            asm volatile("" : "+v"(p));                // keeps the broadcast (and the wait for the atomic) here
+            nb0 = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);   // added here: a VALU use next to the atomic would wait for it there
+            nin = 0;
+        }
+    };
+    // Rows come in through a buffer descriptor rebased per batch (wave-uniform, so the 4 GiB offset
+    // range is per batch, not per matrix): rows past N read as zeros by the hardware range check, one
+    // per-lane offset serves every chunk (immediate offsets), and nothing needs a 64-bit address.
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    f32x4 xn[R / 8];                                   // rows of the next batch, in flight
+    uint32_t ln = 0u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {      // bytes from row bb*32 to the end, clamped
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    auto fetch = [&](uint64_t bb) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j)
+            xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    uint64_t b = block0;
+    fetch(b);
+
+    while (b < a.nbatches) {
+        uint64_t nb0;
+        uint32_t nin;
+        successor(nb0, nin);
+        const uint64_t bnext = nb0 + nin;
+        f32x4 xf[R / 8];
+        using f32x2 = __attribute__((ext_vector_type(2))) float;
+        f32x2 ss2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < R / 8; ++j) {
+            xf[j] = xn[j];
+            const f32x2 lo = {xf[j][0], xf[j][1]}, hi = {xf[j][2], xf[j][3]};
+            ss2 = __builtin_elementwise_fma(lo, lo, ss2);
+            ss2 = __builtin_elementwise_fma(hi, hi, ss2);
+        }
+        const uint32_t label = ln;
+        float ss = ss2[0] + ss2[1];
+        ss += xor32(ss);                               // ||x||^2, the same value in both lanes of the pair
+        const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge rows: exact scan at the end
+        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+        lap(0);                                        // 0: delivery of this batch's rows
+        // vmcnt counts in issue order: the atomic goes out only after this batch's rows have been waited
+        // for, or that wait would include the atomic's own round trip
+        asm volatile("" ::: "memory");
+        if (nin == 0) request();                       // the block after the one just taken
+        fetch(bnext);
+        lap(1);                                        // 1: issue of the next batch's loads
+
+        Keys2 ku;
+        KeysM km;
+        f32x16 acc0, acc1;
+        f32x4 a0 = *(const f32x4 *)(img + Gm::chunk_off(s_col, h));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(img + Gm::W_FLOATS + 8 * g + 4 * h);
+            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;             // "tile -1": its keys never win
+        const float *tprev = img;
+        uint32_t tid = 0;
+        for (uint32_t t = 0; t < ntiles; t += 2) {
+            const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+            const float *tile1 = tile + Gm::TILE_FLOATS;
+            const float *next = t + 2 < ntiles ? tile1 + Gm::TILE_FLOATS : img;
+            // tile t computes into acc0 while tile t-1 (in acc1) is screened; acc1 leaves as the init column of t+1
+            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, xf, acc0, acc1, a0, s_col, h, ku, km);
+            // tile t+1 computes into acc1 while tile t (in acc0) is screened; acc0 leaves as the init column of t+2
+            half_step<R, MATCHED>(tile1, next, tile, t, label, xf, acc1, acc0, a0, s_col, h, ku, km);
+            tprev = tile1;
+            tid = t + 1;
+        }
+        last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+        lap(2);                                        // 2: tile loop
+
+        Best1 wp, wn;
+        finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+        settle_ties<MATCHED>(a, label, wp, wn);
+        {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
+            const int rec = (int)records(b, 4u);
+            const uint32_t so = (uint32_t)s_col * 4u;
+            auto put = [&](void *base, uint32_t bits) {
+                __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+            };
+            if (h == 0) {
+                if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+            } else {
+                if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+            }
+        }
+        lap(3);                                        // 3: batch epilogue
+        b = bnext;
+        block0 = nb0;
+        in_block = nin;
+    }
+    if (DIAG && a.dbg && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 4; ++i) d[i] = tm[i];
+        d[0] = r_begin - r_entry;                          // image load, 100 MHz ticks
+        d[4] = stamp() - t_begin;                          // shader cycles of the batch loop
+        d[5] = __builtin_amdgcn_s_memrealtime() - r_begin; // the same span in 100 MHz ticks
+        d[6] = r_begin;
+        d[7] = r_begin + d[5];
+    }
+}
+
+namespace {
+template <int R, int S>
+hipError_t launch_resident(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;                        // one batch of S*32 samples per wave
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);          // one 512-thread workgroup per CU
+    if (matched)
+        hipLaunchKernelGGL((k_resident<R, S, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_resident<R, S, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int R, bool DIAG>
+hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (DIAG && getenv("VQHIP_NW4"))
+        hipLaunchKernelGGL((k_resident_pipe<R, false, true, 4>), dim3(grid), dim3(256), 0, st, a);
+    else if (DIAG)
+        hipLaunchKernelGGL((k_resident_pipe<R, false, true>), dim3(grid), dim3(512), 0, st, a);
+    else if (matched)
+        hipLaunchKernelGGL((k_resident_pipe<R, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_resident_pipe<R, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn resident_launcher(int R, int *samples_per_batch)
+{
+    constexpr int S = 2;
+    *samples_per_batch = S * 32;
+    switch (R) {
+    case 16: return &launch_resident<16, S>;
+    case 32: return &launch_resident<32, S>;
+    case 64: return &launch_resident<64, S>;
+    case 128: return &launch_resident<128, S>;
+    default: return nullptr;
+    }
+}
+
+LaunchFn resident_pipe_launcher(int R, bool diag)
+{
+    switch (R) {
+    case 16: return diag ? &launch_resident_pipe<16, true> : &launch_resident_pipe<16, false>;
+    case 32: return diag ? &launch_resident_pipe<32, true> : &launch_resident_pipe<32, false>;
+    case 64: return diag ? &launch_resident_pipe<64, true> : &launch_resident_pipe<64, false>;
+    case 128: return diag ? &launch_resident_pipe<128, true> : &launch_resident_pipe<128, false>;
+    default: return nullptr;
+    }
+}
+
+}  // namespace vq

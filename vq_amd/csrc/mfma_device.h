@@ -1,0 +1,543 @@
+// Device-side building blocks shared by the MFMA kernels of libvqhip (gfx950): fragment types, the kernel
+// argument block, running minima, packed screening keys, the tile MFMA loop, exact re-measurement, and
+// the pipelined tile step of the LDS-resident kernels.  Geometry: engine.h.  Included by the kernels_*.hip
+// translation units only; everything here is __device__ __forceinline__ (or constexpr) in an unnamed namespace.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <type_traits>
+
+#include "engine.h"
+#include "mfma_host.h"
+#include "vq_common.h"
+
+namespace vq {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct EngineArgs {
+    const float *X;           // N x D samples (row stride D)
+    uint64_t N;
+    uint32_t D;               // actual sample length (multiple of 4, <= R1)
+    const uint32_t *y;        // sample class ids (matched) or null
+    const float *img1;        // stage-1 groups: prototypes (EUCLID), Omega rows (OMEGA), Omega_j rows (LOCAL)
+    uint32_t ngroups1;
+    const float *img2;        // stage-2 groups: projected prototypes (OMEGA)
+    uint32_t ngroups2;
+    const float *plain;       // K x ldp rows for the exact re-measurement (W, or P = W.Omega^T), zero padded
+    uint32_t ldp;
+    uint32_t K;               // actual number of prototypes
+    uint32_t tiles_per_proto; // LOCAL: 32-row tiles per Omega_j
+    uint64_t nbatches;
+    Outputs out;
+    float wmax2;              // largest ||w_k||^2 (screening error bound)
+    float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
+    uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
+    // Prototypes whose search-space rows are identical (null when the model has none): dup_first[k] = lowest
+    // index with k's row, dup_next[k] = next higher index with it.  See settle_ties.
+    const uint32_t *dup_first, *dup_next;
+    const uint32_t *cls;      // K class ids (labelled models)
+    unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ uint32_t xor32(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 32, 64); }
+
+__device__ __forceinline__ bool lexless(float av, uint32_t ai, float bv, uint32_t bi)
+{
+    return av < bv || (av == bv && ai < bi);
+}
+
+__device__ __forceinline__ unsigned long long stamp()
+{
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Running best two (value, index) of a lane.  Offers arrive with increasing index, so strict '<'
+// keeps the lower index on ties (helpers.rs:70); NaN never enters.
+struct Top2 {
+    float b1, b2;
+    uint32_t i1, i2;
+    __device__ Top2() : b1(INFINITY), b2(INFINITY), i1(0u), i2(0u) {}
+    __device__ __forceinline__ void offer(float v, uint32_t k)
+    {
+        const bool c1 = v < b1, c2 = v < b2;
+        b2 = c1 ? b1 : (c2 ? v : b2);
+        i2 = c1 ? i1 : (c2 ? k : i2);
+        b1 = c1 ? v : b1;
+        i1 = c1 ? k : i1;
+    }
+    // union with the partner lane's pair (the other 16 rows of every tile)
+    __device__ __forceinline__ void merge_halves()
+    {
+        const float o1 = xor32(b1), o2 = xor32(b2);
+        const uint32_t oi1 = xor32(i1), oi2 = xor32(i2);
+        float f, s;
+        uint32_t fi, si;
+        if (lexless(o1, oi1, b1, i1)) {
+            f = o1; fi = oi1;
+            if (lexless(b1, i1, o2, oi2)) { s = b1; si = i1; } else { s = o2; si = oi2; }
+        } else {
+            f = b1; fi = i1;
+            if (lexless(o1, oi1, b2, i2)) { s = o1; si = oi1; } else { s = b2; si = i2; }
+        }
+        b1 = f; i1 = fi; b2 = s; i2 = si;
+    }
+};
+
+struct Best1 {
+    float d;
+    uint32_t i;
+    __device__ Best1() : d(INFINITY), i(0u) {}                          // helpers.rs:58-59
+    __device__ __forceinline__ void offer(float v, uint32_t k)
+    {
+        const bool c = v < d;                                            // helpers.rs:70
+        d = c ? v : d;
+        i = c ? k : i;
+    }
+    __device__ __forceinline__ void merge_halves()
+    {
+        const float o = xor32(d);
+        const uint32_t oi = xor32(i);
+        if (lexless(o, oi, d, i)) { d = o; i = oi; }
+    }
+};
+
+// Exact ties between identical prototypes.  The packed keys order equal scores by position inside the
+// tile before tile number, and keep only two (labelled searches: one) candidates, so among three
+// identical rows the one found need not be the first.  Identical rows have bit-identical distances, so
+// the winner is moved to the first ELIGIBLE prototype with its row (helpers.rs:70: strict '<' keeps the
+// first; helpers.rs:113 / :122: eligibility).  Costs one null test per batch for models without duplicates.
+template <bool MATCHED>
+__device__ __forceinline__ void settle_ties(const EngineArgs &a, uint32_t label, Best1 &wp, Best1 &wn)
+{
+    if (a.dup_first == nullptr) return;
+    auto lowest = [&](uint32_t k, bool want_match) {
+        uint32_t i = a.dup_first[k];
+        while (i != k && MATCHED && (a.cls[i] == label) != want_match) i = a.dup_next[i];
+        return i;
+    };
+    if (wp.d < INFINITY) wp.i = lowest(wp.i, true);
+    if (MATCHED && wn.d < INFINITY) wn.i = lowest(wn.i, false);
+}
+
+// ---- packed screening keys (what they are and why: the comment above k_resident_pipe)
+// Keys are f32 bit patterns and are compared AS FLOATS (v_min_f32 / v_med3_f32), so a score may have
+// either sign and the accumulators start at the plain ||w_k||^2 column.  Nothing that is screened may be
+// a NaN pattern (v_med3_f32 returns the minimum when it sees one): pad rows and the "tile before the
+// first" score PAD_SCORE, finite and above every real score (< 1e38 by ss_limit), instead of +INF,
+// whose pattern with position bits set is a NaN.  NaN / INF scores come only from samples that are
+// sent to the exact scan anyway.
+constexpr uint32_t KEY_NONE = 0x7F800000u;           // +INF: "no candidate yet"
+constexpr float KEY_VALID_F = 1.0e38f;               // keys of real prototypes are below this
+struct Keys2 {                       // unlabelled search: best two keys and their tiles
+    uint32_t b1 = KEY_NONE, b2 = KEY_NONE, t1 = 0u, t2 = 0u;
+};
+struct KeysM {                       // labelled search: best key with cls == y, best with cls != y
+    uint32_t p = KEY_NONE, n = KEY_NONE, tp = 0u, tn = 0u;
+};
+__device__ __forceinline__ bool key_valid(uint32_t key) { return __builtin_bit_cast(float, key) < KEY_VALID_F; }
+
+__device__ __forceinline__ uint32_t pack_key(float score, uint32_t o)
+{
+    uint32_t key;                                   // (bits & ~15) | o in one instruction
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(score), "s"(0xFFFFFFF0u), "n"(o));
+    return key;
+}
+__device__ __forceinline__ uint32_t kmin(uint32_t x, uint32_t y)                     // minimum as floats
+{
+    uint32_t r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// The 16 scores of one finished tile offered to the lane's best two keys: position bits in, median, minimum
+// (3 VALU per score).  One asm statement: the compiler pads a wait state behind every inline-asm result
+// that the next instruction reads, and the chain b1 -> b1 would collect one per score.  PRE_NOPS: wait
+// states for accumulators that the MFMA right in front of the statement has written.
+template <int PRE_NOPS = 0>
+__device__ __forceinline__ void screen16(const f32x16 &sc, Keys2 &ku)
+{
+    uint32_t t0, t1;
+    if constexpr (PRE_NOPS > 0) asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
+    asm(
+        "v_and_or_b32 %[t0], %[s0], %[m], 0\n\t"
+        "v_and_or_b32 %[t1], %[s1], %[m], 1\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s2], %[m], 2\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s3], %[m], 3\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s4], %[m], 4\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s5], %[m], 5\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s6], %[m], 6\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s7], %[m], 7\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s8], %[m], 8\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s9], %[m], 9\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s10], %[m], 10\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s11], %[m], 11\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s12], %[m], 12\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s13], %[m], 13\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_and_or_b32 %[t0], %[s14], %[m], 14\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        "v_and_or_b32 %[t1], %[s15], %[m], 15\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
+        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+        : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [s0] "v"(sc[0]), [s1] "v"(sc[1]), [s2] "v"(sc[2]), [s3] "v"(sc[3]), [s4] "v"(sc[4]), [s5] "v"(sc[5]), [s6] "v"(sc[6]), [s7] "v"(sc[7]), [s8] "v"(sc[8]), [s9] "v"(sc[9]), [s10] "v"(sc[10]), [s11] "v"(sc[11]), [s12] "v"(sc[12]), [s13] "v"(sc[13]), [s14] "v"(sc[14]), [s15] "v"(sc[15]), [m] "s"(0xFFFFFFF0u));
+}
+// After a tile's scores went in: which tile do the best two keys come from now
+__device__ __forceinline__ void settle_tiles(Keys2 &ku, const Keys2 &before, uint32_t tile_id)
+{
+    const bool c1 = ku.b1 != before.b1, c2 = ku.b2 != before.b2;
+    const uint32_t demoted = ku.b2 == before.b1 ? before.t1 : tile_id;
+    ku.t2 = c1 ? demoted : (c2 ? tile_id : before.t2);
+    ku.t1 = c1 ? tile_id : before.t1;
+}
+
+__device__ __forceinline__ uint32_t key_row(uint32_t key, uint32_t tile, int h)   // prototype index of a key
+{
+    const uint32_t o = key & 15u;
+    return tile * 32u + ((o >> 2) << 3) + (o & 3u) + 4u * (uint32_t)h;
+}
+
+__device__ __forceinline__ bool keyless(uint32_t ak, uint32_t ai, uint32_t bk, uint32_t bi)
+{
+    const float a = __builtin_bit_cast(float, ak), b = __builtin_bit_cast(float, bk);
+    return a < b || (a == b && ai < bi);
+}
+
+// LDS-DMA of one stage (BYTES, multiple of 16) from its pre-swizzled global image: a linear copy,
+// 1 KiB per wave-instruction, pieces dealt round-robin to the 4 waves.
+template <int BYTES>
+__device__ __forceinline__ void stage_group(char *lds_dst, const char *gsrc, int wave, int lane)
+{
+    constexpr int PIECES = (BYTES + 1023) / 1024;
+#pragma unroll
+    for (int i = 0; i < (PIECES + 3) / 4; ++i) {
+        const int p = i * 4 + wave;
+        const int off = p * 1024 + lane * 16;
+        if (p < PIECES && off < BYTES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + off),
+                                             (__attribute__((address_space(3))) void *)(lds_dst + p * 1024), 16, 0, 0);
+    }
+}
+
+// acc[s] (+)= tile . xf[s]^T for one 32-row tile in LDS; accumulators start at the tile's init column.
+template <int R, int S>
+__device__ __forceinline__ void tile_mma(const float *tile, const f32x4 (&xf)[S][R / 8], f32x16 (&acc)[S], int row, int h)
+{
+    using Gm = Geom<R>;
+    const float *tail = tile + Gm::W_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
+            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
+        }
+    }
+    const float *rowp = tile + Gm::chunk_off(row, h);
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 a = *(const f32x4 *)(rowp + 8 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], xf[s][j][e], acc[s], 0, 0, 0);
+    }
+}
+
+// Exact distance of one sample (fragment xf, this lane's half of the chunks) to row `k` of the
+// zero-padded plain matrix: sum over the lane's chunks, then both halves added.
+template <int R>
+__device__ __forceinline__ float exact_sq(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t k, int h)
+{
+    const float *w = plain + (size_t)k * ldp;
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 wv = *(const f32x4 *)(w + 4 * (2 * j + h));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = wv[e] - xf[j][e];
+            p = fmaf(d, d, p);
+        }
+    }
+    return p + xor32(p);
+}
+
+// Full exact scan in index order (helpers.rs:55-77 in f32): used only when the screening scores of
+// a sample are unusable (-INF from an infinite input, or a non-finite re-measured winner).
+template <int R, bool ROOT>
+__device__ __forceinline__ void exact_scan(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t K, int h,
+                                        const uint32_t *cls_plain, bool matched, uint32_t label, Best1 &pos, Best1 &neg)
+{
+    pos = Best1();
+    neg = Best1();
+    for (uint32_t k = 0; k < K; ++k) {
+        float d = exact_sq<R>(xf, plain, ldp, k, h);
+        if (ROOT) d = sqrtf(d);
+        if (!matched || cls_plain[k] == label) pos.offer(d, k);
+        else neg.offer(d, k);
+    }
+}
+
+// ------------------------------------------------------------------------------ LDS-resident images
+// Euclidean models whose whole tile image fits in LDS (K * D <= ~36K floats; config 2 is 130 KiB):
+// "prototypes staged in LDS" once per workgroup, then every wave is independent -- no per-tile DMA,
+// no barriers, and the exact re-measurement of the candidates reads its rows from LDS as well.
+// One 512-thread workgroup per CU = 2 waves per SIMD sharing one copy of the prototypes.
+
+template <int R>
+__device__ __forceinline__ float exact_sq_lds(const f32x4 (&xf)[R / 8], const float *img, uint32_t k, int h)
+{
+    using Gm = Geom<R>;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const uint32_t r = k & 31u;
+    const float *rowp = img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::chunk_off((int)r, h);
+    // two partial sums, v_pk_fma_f32: 4 VALU per chunk instead of 8 (VALU time is matrix-pipe time here)
+    f32x2 p = {0.0f, 0.0f};
+    const f32x2 half = {0.5f, 0.5f};
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 v = *(const f32x4 *)(rowp + 8 * j);                          // v = -2 w
+        const f32x2 d0 = __builtin_elementwise_fma(half, f32x2{v[0], v[1]}, f32x2{xf[j][0], xf[j][1]});   // x - w, exact scaling
+        const f32x2 d1 = __builtin_elementwise_fma(half, f32x2{v[2], v[3]}, f32x2{xf[j][2], xf[j][3]});
+        p = __builtin_elementwise_fma(d0, d0, p);
+        p = __builtin_elementwise_fma(d1, d1, p);
+    }
+    const float t = p[0] + p[1];
+    return t + xor32(t);
+}
+
+// ------------------------------------------------------------------------------ pipelined tile step of the resident kernels
+// Same contract as k_resident.  What it is built around (measured on MI355X):
+//   * v_mfma_f32_32x32x2_f32 runs at the f32 vector rate and does not co-execute with VALU work of
+//     the same SIMD: kernel time ~ 64 cycles per MFMA + 4 cycles per VALU instruction.  So the
+//     screening of the scores is cut to 4 VALU per score (packed keys, below) instead of 8.
+//   * every wave of the chip loading its samples and then computing, in lockstep, leaves HBM idle
+//     during the search and the matrix pipe idle during the loads: the next batch's rows are
+//     fetched into a second register set while the current batch is searched.
+//   * the two waves of a SIMD do not share the matrix pipe evenly, so batches are claimed from a
+//     queue instead of being dealt out.
+//
+// Packed keys.  A finished score is ||w_k||^2 - 2 x.w_k (the accumulator starts at the ||w_k||^2 column of
+// the tile).  The low 4 mantissa bits of its f32 pattern are replaced by the row's position o among the
+// lane's 16 rows of the tile, and the patterns are compared as floats: v_min_f32 / v_med3_f32 keep the
+// best two keys of a lane (3 VALU per score, no shift of the scores to one sign), and which TILE they
+// came from is settled once per tile by comparing the pair before and after.  Scores closer than the 4
+// dropped bits are ordered by o, not by value or index: both candidates are re-measured exactly and
+// compared like helpers.rs:70 where they are close, and exact ties between identical rows are settled by
+// settle_ties.  Pad rows score PAD_SCORE; samples whose ||x||^2 is not safely finite (the only source of
+// NaN / INF scores) go to the exact in-order scan.
+// On entry:  acc = accumulator-init column of `tile`, a0 = this lane's chunk 0 of `tile`,
+//            prev = finished scores of tile number `tprev_id` (class ids in tprev's tail).
+// On exit:   acc = scores of (tile, xf), prev = init column of `next`, a0 = chunk 0 of `next`.
+template <int R, bool MATCHED>
+__device__ __forceinline__ void half_step(const float *tile, const float *next, const float *tprev, uint32_t tprev_id,
+                                          uint32_t label, const f32x4 (&xf)[R / 8], f32x16 &acc, f32x16 &prev,
+                                          f32x4 &a0, int row, int h, Keys2 &ku, KeysM &km)
+{
+    using Gm = Geom<R>;
+    constexpr int NM = R / 2;                          // MFMAs of this half-step
+    constexpr int SPAN = R >= 32 ? NM / 2 : NM;        // the 16 keys are spread over the first SPAN MFMAs
+    constexpr int CI = NM / 2;                         // MFMA after which the next init column is fetched
+    const float *rowp = tile + Gm::chunk_off(row, h);
+    f32x4 acur = a0, anext = a0;
+    f32x16 cnext;
+    const Keys2 ou = ku;
+    const KeysM om = km;
+    // class ids of the screened tile's rows, one group of 4 rows ahead of the keys that use them
+    const uint32_t *tcls = (const uint32_t *)(tprev + Gm::W_FLOATS) + 32 + 4 * h;
+    u32x4 cgc = {0u, 0u, 0u, 0u}, cgn = {0u, 0u, 0u, 0u};
+    if (MATCHED) cgn = *(const u32x4 *)tcls;
+    static_for<0, NM>([&](auto ii) {
+        constexpr int i = decltype(ii)::value, j = i / 4, e = i % 4;
+        if constexpr (e == 0) {
+            acur = anext;
+            if constexpr (j + 1 < R / 8)
+                anext = *(const f32x4 *)(rowp + 8 * (j + 1));
+            else
+                a0 = *(const f32x4 *)(next + Gm::chunk_off(row, h));
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[e], xf[j][e], acc, 0, 0, 0);
+        if constexpr (!MATCHED) {
+            if constexpr (i == 0) {                       // behind the first MFMA: prev's own MFMAs are long done
+                screen16(prev, ku);
+                settle_tiles(ku, ou, tprev_id);
+            }
+        } else {
+            constexpr int o0 = i * 16 / SPAN < 16 ? i * 16 / SPAN : 16;
+            constexpr int o1 = (i + 1) * 16 / SPAN < 16 ? (i + 1) * 16 / SPAN : 16;
+            static_for<o0, o1>([&](auto oo) {
+                constexpr int o = decltype(oo)::value;
+                const uint32_t key = pack_key(prev[o], o);
+                if constexpr ((o & 3) == 0) {
+                    cgc = cgn;
+                    if constexpr (o + 4 < 16) cgn = *(const u32x4 *)(tcls + 8 * ((o >> 2) + 1));
+                }
+                const bool match = cgc[o & 3] == label;           // helpers.rs:113 / :122
+                const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
+                km.p = kmin(km.p, kp);
+                km.n = kmin(km.n, kn);
+            });
+            if constexpr (o0 < 16 && o1 == 16) {          // all 16 keys of the tile are in: settle the tiles
+                km.tp = km.p != om.p ? tprev_id : om.tp;
+                km.tn = km.n != om.n ? tprev_id : om.tn;
+            }
+        }
+        if constexpr (i == CI) {
+            const float *tail = next + Gm::W_FLOATS;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+                cnext[4 * g + 0] = ci[0]; cnext[4 * g + 1] = ci[1];
+                cnext[4 * g + 2] = ci[2]; cnext[4 * g + 3] = ci[3];
+            }
+        }
+    });
+    prev = cnext;
+}
+
+// Screening of the last tile of a batch (no MFMAs left to run beside it).
+template <int R, bool MATCHED>
+__device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tprev, uint32_t tprev_id, uint32_t label, int h,
+                                            Keys2 &ku, KeysM &km)
+{
+    const uint32_t *tcls = (const uint32_t *)(tprev + Geom<R>::W_FLOATS) + 32 + 4 * h;
+    const Keys2 ou = ku;
+    const KeysM om = km;
+    if constexpr (!MATCHED) {
+        screen16<1>(prev, ku);
+        settle_tiles(ku, ou, tprev_id);
+    } else {
+        static_for<0, 16>([&](auto oo) {
+            constexpr int o = decltype(oo)::value;
+            const uint32_t key = pack_key(prev[o], o);
+            const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;
+            const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
+            km.p = kmin(km.p, kp);
+            km.n = kmin(km.n, kn);
+        });
+        km.tp = km.p != om.p ? tprev_id : om.tp;
+        km.tn = km.n != om.n ? tprev_id : om.tn;
+    }
+}
+
+// Final step of a batch: the lane pair agrees on the candidates, re-measures them in the direct
+// (x - w)^2 form from the LDS image, roots, compares like helpers.rs:70.
+template <int R, bool MATCHED, bool ROOT = true>
+__device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h,
+                                            bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
+{
+    using Gm = Geom<R>;
+    // helpers.rs:23 (rooted) vs helpers.rs:44 (squared)
+    auto dist = [&](uint32_t k) {
+        const float d = exact_sq_lds<R>(xf, img, k, h);
+        return ROOT ? sqrtf(d) : d;
+    };
+    if (!MATCHED) {
+        // this lane's two candidates and the partner lane's, best two of the four by (key, index)
+        const uint32_t k1 = key_row(ku.b1, ku.t1, h), k2 = key_row(ku.b2, ku.t2, h);
+        const uint32_t pb1 = xor32(ku.b1), pb2 = xor32(ku.b2), pk1 = xor32(k1), pk2 = xor32(k2);
+        uint32_t f, fi, sd, si;
+        if (keyless(pb1, pk1, ku.b1, k1)) {
+            f = pb1; fi = pk1;
+            if (keyless(ku.b1, k1, pb2, pk2)) { sd = ku.b1; si = k1; } else { sd = pb2; si = pk2; }
+        } else {
+            f = ku.b1; fi = k1;
+            if (keyless(pb1, pk1, ku.b2, k2)) { sd = pb1; si = pk1; } else { sd = ku.b2; si = k2; }
+        }
+        if (key_valid(f) && !unsafe) {
+            const float d1 = dist(fi);
+            wp.d = d1; wp.i = fi;
+            // The runner-up is re-measured only where it can still win: a key differs from the true
+            // ||w||^2 - 2 x.w by less than margin/2 (f32 accumulation of 2 x.w, rounding of the
+            // init column, the 4 truncated bits), so a gap above `margin` decides the order already.
+            // Decided per wave: the re-measurement is 80 VALU + 16 LDS reads for every lane or for none.
+            const bool close = key_valid(sd) && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
+            if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+                if (key_valid(sd)) {
+                    const float d2 = dist(si);
+                    if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+                }
+            }
+            unsafe = !(wp.d < INFINITY);
+        } else {
+            unsafe = true;
+        }
+    } else {
+        uint32_t kp = key_row(km.p, km.tp, h), kn = key_row(km.n, km.tn, h), p = km.p, n = km.n;
+        const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
+        if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
+        if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
+        if (key_valid(p)) {
+            wp.d = dist(kp); wp.i = kp;
+            unsafe |= !(wp.d < INFINITY);
+        }
+        if (key_valid(n)) {
+            wn.d = dist(kn); wn.i = kn;
+            unsafe |= !(wn.d < INFINITY);
+        }
+    }
+    if (unsafe) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
+        wp = Best1();
+        wn = Best1();
+        for (uint32_t k = 0; k < K; ++k) {
+            const float d = dist(k);
+            const uint32_t ck = MATCHED ? ((const uint32_t *)(img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::W_FLOATS))[32 + (k & 31)] : 0u;
+            if (!MATCHED || ck == label) wp.offer(d, k);
+            else wn.offer(d, k);
+        }
+    }
+}
+
+}  // namespace
+
+}  // namespace vq

@@ -1,0 +1,26 @@
+// Host-side interface between the kernel translation units (kernels_*.hip) and the model builder
+// (engine_host.hip): one launcher per kernel family, looked up by its compile-time shape.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace vq {
+
+struct EngineArgs;
+// Enqueues one pass over a.N samples on `st` (zeroes the batch counter a.queue first where the kernel claims batches).
+using LaunchFn = hipError_t (*)(const EngineArgs &a, bool matched, hipStream_t st);
+
+enum { MODE_EUCLID = 0, MODE_OMEGA = 1, MODE_LOCAL = 2 };
+
+// nullptr when the shape is not instantiated.  samples_per_batch: samples one claimed batch covers.
+LaunchFn streamed_launcher(int mode, int R1, int R2, int *samples_per_batch);    // kernels_engine.hip: k_engine
+LaunchFn resident_launcher(int R, int *samples_per_batch);                       // kernels_resident.hip: k_resident
+LaunchFn resident_pipe_launcher(int R, bool diag);                               // kernels_resident.hip: k_resident_pipe
+LaunchFn omega_pipe_launcher(int R);                                             // kernels_omega.hip: k_omega_pipe
+LaunchFn lowrank_launcher(int R1);                                               // kernels_omega.hip: k_lowrank_pipe
+
+constexpr int RES_BYTES = 156 * 1024;       // LDS one resident workgroup may fill with images
+constexpr float PAD_SCORE = 3.0e38f;        // accumulator init of pad rows: finite, above every real score
+
+}  // namespace vq

@@ -62,7 +62,7 @@ hipError_t launch_assign_local_scalar(const float *dX, uint64_t N, uint32_t D, c
                                       const float *dOms, uint32_t M, const uint32_t *dcls,
                                       const uint32_t *dy, Outputs out, hipStream_t s);
 
-// ---------------------------------------------------------------- MFMA engine (kernels_mfma.hip)
+// ---------------------------------------------------------------- MFMA kernels (engine_host.hip builds the model; kernels_engine / _resident / _omega.hip)
 struct EngineModel;   // device tile images + shapes, built by the engine from host copies
 
 // Returns nullptr (and sets why) when the shape is not eligible for the engine.
