@@ -597,3 +597,55 @@ def test_lowrank_ties_nan_and_streamed_fallback(ctx):
     assert ctx.last_kernel == "mfma_omega"
     rep = parity.compare(idx, dist, *oracle.assign(X2, W2, omega=Om2, threads=8), atol=2e-6)
     assert rep.ok, str(rep)
+
+
+# ------------------------------------------------------------------ seeded sweep over shapes (kernel selection edges)
+
+def _sweep_shapes():
+    rng = np.random.default_rng(2024)
+    out = []
+    for i in range(24):
+        kind = ("none", "global", "local")[i % 3]
+        D = int(rng.choice([4, 8, 12, 16, 20, 32, 48, 64, 100, 128, 192, 256]))
+        K = int(rng.choice([1, 2, 5, 31, 32, 33, 64, 100, 257, 300])) if kind != "local" else int(rng.choice([1, 2, 5, 9]))
+        M = 0 if kind == "none" else int(rng.choice([1, 4, 7, 16, 17, 32, D])) if kind == "global" else int(rng.choice([3, 8, min(D, 32)]))
+        M = min(M, 256)
+        N = int(rng.choice([1, 31, 65, 257, 700]))
+        out.append((N, D, K, M, kind))
+    return out
+
+
+@pytest.mark.parametrize("shape", _sweep_shapes(), ids=lambda s: "n%d_d%d_k%d_m%d_%s" % s)
+def test_shape_sweep_against_oracle(ctx, shape):
+    """Unstructured data over a seeded sweep of (N, D, K, M, model kind): whatever kernel VQHIP_KERNEL_AUTO picks
+    must meet the parity bar, plain and matched, and agree with the scalar kernels' choice of winners wherever
+    the oracle's gap is clear."""
+    N, D, K, M, kind = shape
+    rng = np.random.default_rng(N * 7 + D * 3 + K + M)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    Om = None
+    if kind == "global":
+        Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    elif kind == "local":
+        Om = (rng.uniform(-1, 1, size=(K, M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    atol = 0.0 if kind == "none" else 2e-6
+    o_plain = oracle.assign(X, W, omega=Om, threads=8)
+    for policy in POLICIES:
+        ctx.set_kernel_policy(policy)
+        ctx.set_prototypes(W)
+        if kind == "global":
+            ctx.set_omega(Om)
+        elif kind == "local":
+            ctx.set_local_omegas(Om)
+        idx, dist = ctx.assign(X)
+        rep = parity.compare(idx, dist, *o_plain, atol=atol)
+        assert rep.ok, f"{shape} {ctx.last_kernel}: {rep}"
+        ctx.set_labels(cls)
+        jp, dp, jn, dn = ctx.assign_matched(X, y)
+        for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+            o = oracle.assign(X, W, omega=Om, proto_cls=cls, labels=y, matching=matching, threads=8)
+            rep = parity.compare(j, d, *o, atol=atol)
+            assert rep.ok, f"{shape} {ctx.last_kernel} matching={matching}: {rep}"
