@@ -23,6 +23,16 @@ flops = {"none": 2*cfg.K*cfg.D, "global": 2*cfg.M*cfg.D + 2*cfg.K*cfg.M, "local"
 print(f"{name} kernel={ctx.last_kernel} N={N} ms={ms:.3f} samples/s={N/ms*1e3:.4g} TFLOP/s={N*flops/ms/1e9:.1f} GB/s={N*(cfg.D*4+8)/ms/1e6:.0f}")
 ok = (idx.cpu().numpy() == np.arange(N) % cfg.K).mean()
 print("frac idx == i mod K:", ok)
+if len(sys.argv) > 3 and sys.argv[3] == "matched":
+    y = torch.from_numpy(synth.sample_labels(m, 0, N).view(np.int32)).cuda()
+    jn = torch.empty(N, dtype=torch.int32, device="cuda"); dn = torch.empty(N, dtype=torch.float32, device="cuda")
+    for _ in range(2): ctx.assign_into(X, idx, dist, y=y, jneg_out=jn, dneg_out=dn)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(K): ctx.assign_into(X, idx, dist, y=y, jneg_out=jn, dneg_out=dn)
+    ev[1].record(); torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / K
+    print(f"{name} matched (both searches) kernel={ctx.last_kernel} N={N} ms={ms:.3f} samples/s={N/ms*1e3:.4g} TFLOP/s={N*flops/ms/1e9:.1f}")
 if len(sys.argv) > 3 and sys.argv[3] == "project" and cfg.omega == "global":
     from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
     for which, width, fl, nm in ((PROJECT_LAMBDA, cfg.D, 2 * cfg.D * cfg.D, "project(Lambda)"), (PROJECT_OMEGA, cfg.M, 2 * cfg.M * cfg.D, "project_omega")):
