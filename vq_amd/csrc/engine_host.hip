@@ -33,6 +33,9 @@ struct EngineModel {
 
 namespace {
 
+// tiles of 32 prototypes a resident kernel searches (the images are padded further, to whole stage groups)
+uint32_t res_tiles(uint32_t K) { return (K + 31) / 32; }
+
 int pad_pow2(uint32_t v, int lo)
 {
     int r = lo;
@@ -82,12 +85,11 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
                  const std::vector<uint32_t> &cls)
 {
     if (m.R1 != (uint32_t)R1) return false;
-    // an even number of tiles: the pipelined kernel ping-pongs two accumulators (pad rows score +INF)
     img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
-                           m.ngroups1, ((size_t)m.K + 63) / 64 * 64);
+                           m.ngroups1);
     m.launch = streamed_launcher(MODE_EUCLID, R1, R1, &m.samples_per_batch);
     if constexpr (R1 < 256) {
-        if ((size_t)m.ngroups1 * Geom<R1>::STAGE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
+        if ((size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
             m.launch = resident_launcher(R1, &m.samples_per_batch);
             m.name = "mfma_euclid_lds";
             if (m.D == (uint32_t)R1 && !getenv("VQHIP_NO_PIPE")) {       // unpadded rows: the pipelined kernel
@@ -131,7 +133,7 @@ bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &
     uint32_t ngroups2 = 0;
     std::vector<float> pimg = build_images<16>(Pp.data(), m.K, 16, 16, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
                                                PAD_SCORE, ngroups2);
-    if (pimg.size() * sizeof(float) + (size_t)16 * ROWF * sizeof(float) > (size_t)RES_BYTES) return false;
+    if ((size_t)res_tiles(m.K) * Geom<16>::TILE_BYTES + (size_t)16 * ROWF * sizeof(float) > (size_t)RES_BYTES) return false;
     img2 = std::move(pimg);
     m.ngroups2 = ngroups2;
     img1.assign((size_t)16 * ROWF, 0.0f);                              // Omega rows, row stride R1 + 4
@@ -153,8 +155,8 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     if (m.D != (uint32_t)R || m.R2 != (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;
     uint32_t ngroups2 = 0;
     std::vector<float> pimg = build_images<R>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
-                                              PAD_SCORE, ngroups2, ((size_t)m.K + 63) / 64 * 64);
-    if (pimg.size() * sizeof(float) > (size_t)RES_BYTES) return false;
+                                              PAD_SCORE, ngroups2);
+    if ((size_t)res_tiles(m.K) * Geom<R>::TILE_BYTES > (size_t)RES_BYTES) return false;
     img2 = std::move(pimg);
     m.ngroups2 = ngroups2;
     // Omega as A-fragment pieces: piece (t, j), lane (row, h) = Omega[32 t + row][4 (2 j + h) .. + 3]
@@ -333,6 +335,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.img2 = m->img2; a.ngroups2 = m->ngroups2;
     a.plain = m->plain; a.ldp = m->ldp;
     a.K = m->K; a.tiles_per_proto = m->tiles_per_proto;
+    a.res_tiles = res_tiles(m->K);
     a.nbatches = (N + m->samples_per_batch - 1) / m->samples_per_batch;
     a.out = out;
     a.ss_limit = m->ss_limit;

@@ -261,6 +261,9 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                                 settle_tiles(ku[s], ou[s], tile_id);
                             }
                         } else {
+                            // the keys are packed by inline asm, which the compiler does not count as a reader of
+                            // the accumulators the MFMA right in front has written: wait states by hand
+                            asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
                             static_for<0, 16>([&](auto oo) {
                                 constexpr int o = decltype(oo)::value;
                                 const uint32_t cls = tcls[8 * (o >> 2) + (o & 3)];

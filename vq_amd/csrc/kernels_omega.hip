@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const int n16 = lane & 15, kg = lane >> 4;
-    const uint32_t ntiles = a.ngroups2 * Gs::G;       // even (G = 8)
+    const uint32_t ntiles = a.res_tiles;
     const uint32_t p_bytes = ntiles * Gs::TILE_BYTES;
 
     {   // both images -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
@@ -162,27 +162,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         // ---- search in the projected space (k_resident_pipe's tile loop at R = 16)
         Keys2 ku;
         KeysM km;
-        f32x16 acc0, acc1;
-        f32x4 a0 = *(const f32x4 *)(img + Gs::chunk_off(s_col, h));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
-            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;
-        const float *tprev = img;
-        uint32_t tid = 0;
-        for (uint32_t t = 0; t < ntiles; t += 2) {
-            const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
-            const float *tile1 = tile + Gs::TILE_FLOATS;
-            const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
-            half_step<16, MATCHED>(tile, tile1, tprev, tid, label, yf, acc0, acc1, a0, s_col, h, ku, km);
-            half_step<16, MATCHED>(tile1, next, tile, t, label, yf, acc1, acc0, a0, s_col, h, ku, km);
-            tprev = tile1;
-            tid = t + 1;
-        }
-        last_screen<16, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+        search_tiles<16, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
 
         Best1 wp, wn;
         finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
@@ -225,7 +205,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
-    const uint32_t ntiles = a.ngroups2 * Gs::G;       // even (host pads)
+    const uint32_t ntiles = a.res_tiles;
 
     {   // prototype image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
         const uint32_t bytes = ntiles * Gs::TILE_BYTES;
@@ -346,27 +326,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         // ---- search in the projected space (k_resident_pipe's tile loop)
         Keys2 ku;
         KeysM km;
-        f32x16 acc0, acc1;
-        f32x4 a0 = *(const f32x4 *)(img + Gs::chunk_off(s_col, h));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 ci = *(const f32x4 *)(img + Gs::W_FLOATS + 8 * g + 4 * h);
-            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;
-        const float *tprev = img;
-        uint32_t tid = 0;
-        for (uint32_t t = 0; t < ntiles; t += 2) {
-            const float *tile = img + (size_t)t * Gs::TILE_FLOATS;
-            const float *tile1 = tile + Gs::TILE_FLOATS;
-            const float *next = t + 2 < ntiles ? tile1 + Gs::TILE_FLOATS : img;
-            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, yf, acc0, acc1, a0, s_col, h, ku, km);
-            half_step<R, MATCHED>(tile1, next, tile, t, label, yf, acc1, acc0, a0, s_col, h, ku, km);
-            tprev = tile1;
-            tid = t + 1;
-        }
-        last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+        search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
 
         Best1 wp, wn;
         finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);

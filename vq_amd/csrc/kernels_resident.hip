@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
-    const uint32_t ntiles = a.ngroups1 * Gm::G;
+    const uint32_t ntiles = a.res_tiles;
     const uint32_t Cact = a.D >> 2;
 
     {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
@@ -129,8 +129,8 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 }
 
 // ------------------------------------------------------------------------------ pipelined resident kernel
-// One wave = one tile of 32 samples per batch.  D == R (host checks); the image has an even number of
-// tiles (the accumulators ping-pong).  a.ss_limit: ||x||^2 below which no score can overflow.
+// One wave = one tile of 32 samples per batch.  D == R (host checks); a.res_tiles tiles of 32
+// prototypes are searched (search_tiles).  a.ss_limit: ||x||^2 below which no score can overflow.
 template <int R, bool MATCHED, bool DIAG = false, int NW = 8>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
 {
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     const unsigned long long r_entry = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
-    const uint32_t ntiles = a.ngroups1 * Gm::G;       // even (host pads)
+    const uint32_t ntiles = a.res_tiles;
 
     {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
         const uint32_t bytes = ntiles * Gm::TILE_BYTES;
@@ -258,29 +258,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
 
         Keys2 ku;
         KeysM km;
-        f32x16 acc0, acc1;
-        f32x4 a0 = *(const f32x4 *)(img + Gm::chunk_off(s_col, h));
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 ci = *(const f32x4 *)(img + Gm::W_FLOATS + 8 * g + 4 * h);
-            acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;             // "tile -1": its keys never win
-        const float *tprev = img;
-        uint32_t tid = 0;
-        for (uint32_t t = 0; t < ntiles; t += 2) {
-            const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
-            const float *tile1 = tile + Gm::TILE_FLOATS;
-            const float *next = t + 2 < ntiles ? tile1 + Gm::TILE_FLOATS : img;
-            // tile t computes into acc0 while tile t-1 (in acc1) is screened; acc1 leaves as the init column of t+1
-            half_step<R, MATCHED>(tile, tile1, tprev, tid, label, xf, acc0, acc1, a0, s_col, h, ku, km);
-            // tile t+1 computes into acc1 while tile t (in acc0) is screened; acc0 leaves as the init column of t+2
-            half_step<R, MATCHED>(tile1, next, tile, t, label, xf, acc1, acc0, a0, s_col, h, ku, km);
-            tprev = tile1;
-            tid = t + 1;
-        }
-        last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+        search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
         lap(2);                                        // 2: tile loop
 
         Best1 wp, wn;

@@ -30,6 +30,7 @@ struct EngineArgs {
     uint32_t ldp;
     uint32_t K;               // actual number of prototypes
     uint32_t tiles_per_proto; // LOCAL: 32-row tiles per Omega_j
+    uint32_t res_tiles;       // resident kernels: tiles of 32 prototypes actually searched, ceil(K / 32)
     uint64_t nbatches;
     Outputs out;
     float wmax2;              // largest ||w_k||^2 (screening error bound)
@@ -467,6 +468,44 @@ __device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tpr
         });
         km.tp = km.p != om.p ? tprev_id : om.tp;
         km.tn = km.n != om.n ? tprev_id : om.tn;
+    }
+}
+
+// The search of one batch over `ntiles` resident tiles (any count >= 1): tile t computes into one accumulator
+// while the finished scores of tile t-1 in the other are screened; an odd last tile runs on its own.
+template <int R, bool MATCHED>
+__device__ __forceinline__ void search_tiles(const float *img, uint32_t ntiles, uint32_t label, const f32x4 (&xf)[R / 8],
+                                             int s_col, int h, Keys2 &ku, KeysM &km)
+{
+    using Gm = Geom<R>;
+    f32x16 acc0, acc1;
+    f32x4 a0 = *(const f32x4 *)(img + Gm::chunk_off(s_col, h));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(img + Gm::W_FLOATS + 8 * g + 4 * h);
+        acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;                 // "tile -1": its keys never win
+    const float *tprev = img;
+    uint32_t tid = 0, t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+        const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+        const float *tile1 = tile + Gm::TILE_FLOATS;
+        const float *next = t + 2 < ntiles ? tile1 + Gm::TILE_FLOATS : img;
+        // tile t computes into acc0 while tile t-1 (in acc1) is screened; acc1 leaves as the init column of t+1
+        half_step<R, MATCHED>(tile, tile1, tprev, tid, label, xf, acc0, acc1, a0, s_col, h, ku, km);
+        // tile t+1 computes into acc1 while tile t (in acc0) is screened; acc0 leaves as the init column of t+2
+        half_step<R, MATCHED>(tile1, next, tile, t, label, xf, acc1, acc0, a0, s_col, h, ku, km);
+        tprev = tile1;
+        tid = t + 1;
+    }
+    if (t < ntiles) {                                                 // odd count: acc0 holds the last tile's init column
+        const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+        half_step<R, MATCHED>(tile, img, tprev, tid, label, xf, acc0, acc1, a0, s_col, h, ku, km);
+        last_screen<R, MATCHED>(acc0, tile, t, label, h, ku, km);
+    } else {
+        last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
     }
 }
 

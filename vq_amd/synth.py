@@ -38,6 +38,7 @@ CONFIGS = {
     "c5": Config("c5", "LGMLVQ", 50_000_000, 128, 64, M=128, omega="local"),
     # small-K Euclidean streaming case (HBM-rate demonstration)
     "c2k32": Config("c2k32", "GLVQ", 10_000_000, 128, 32),
+    "c2k8": Config("c2k8", "GLVQ", 10_000_000, 128, 8),
     # many-prototype Euclidean case (per-batch costs amortised over 128 tiles): kernel tuning only
     "xk4096": Config("xk4096", "GLVQ", 1_000_000, 128, 4096),
 }
