@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
 # device function behind each kernel family name reported by vqhip_last_kernel
-KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "mfma_omega_lds": "k_omega_pipe",
+KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds_staged": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "mfma_omega_lds": "k_omega_pipe",
              "mfma_omega_lowrank_lds": "k_lowrank_pipe", "scalar": "k_assign_scalar"}
 
 

@@ -335,7 +335,8 @@ def test_pipelined_kernel_prototype_counts(ctx, K):
     ctx.set_kernel_policy(KERNEL_AUTO)
     ctx.set_prototypes(W)
     idx, dist = ctx.assign(X)
-    assert ctx.last_kernel == "mfma_euclid_lds_pipe"
+    # one tile of prototypes leaves room in LDS for the rows: they are staged through it (k_resident_pipe STAGED)
+    assert ctx.last_kernel == ("mfma_euclid_lds_staged" if K <= 32 else "mfma_euclid_lds_pipe")
     rep = parity.compare(idx, dist, *oracle.assign(X, W, threads=8))
     assert rep.ok, str(rep)
     y = rng.integers(0, 3, size=N).astype(np.uint32)
@@ -498,11 +499,13 @@ def test_project_local(ctx, shape):
     assert e.value.code == -2
 
 
+@pytest.mark.parametrize("K", [256, 20], ids=["pipe_k256", "staged_k20"])
 @pytest.mark.parametrize("N", [1, 31, 32, 33, 63, 65, 4097])
-def test_pipelined_kernel_row_counts(ctx, N):
-    """Batches of 32 rows claimed in blocks of 2: rows past N are dropped by the buffer range check."""
+def test_pipelined_kernel_row_counts(ctx, N, K):
+    """Batches of 32 rows claimed in blocks of 2: rows past N are dropped by the buffer range check
+    (fragment loads, LDS-DMA pieces of the staged variant, and the stores)."""
     rng = np.random.default_rng(N)
-    D, K = 128, 256
+    D = 128
     W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
     X = rng.uniform(-1, 1, size=(N + 3, D)).astype(np.float32)
     ctx.set_kernel_policy(KERNEL_AUTO)
@@ -513,7 +516,7 @@ def test_pipelined_kernel_row_counts(ctx, N):
     dist = torch.full((N + 3,), -7.0, dtype=torch.float32, device="cuda")
     ctx.assign_into(Xd[:N], idx[:N], dist[:N])
     torch.cuda.synchronize()
-    assert ctx.last_kernel == "mfma_euclid_lds_pipe"
+    assert ctx.last_kernel == ("mfma_euclid_lds_pipe" if K == 256 else "mfma_euclid_lds_staged")
     assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()   # nothing written past N
     rep = parity.compare(idx[:N].cpu().numpy(), dist[:N].cpu().numpy(), *oracle.assign(X[:N], W, threads=8))
     assert rep.ok, str(rep)
@@ -649,3 +652,39 @@ def test_shape_sweep_against_oracle(ctx, shape):
             o = oracle.assign(X, W, omega=Om, proto_cls=cls, labels=y, matching=matching, threads=8)
             rep = parity.compare(j, d, *o, atol=atol)
             assert rep.ok, f"{shape} {ctx.last_kernel} matching={matching}: {rep}"
+
+
+@pytest.mark.parametrize("case", [(5000, 128, 32), (3001, 64, 64), (2500, 64, 7), (1999, 32, 50)], ids=lambda c: "n%d_d%d_k%d" % c)
+def test_staged_kernel(ctx, case):
+    """Few prototypes: rows staged through LDS by 1 KiB LDS-DMA pieces (2 / 4 / 8 rows per piece at D = 128 / 64 / 32).
+    Plain and matched search, NaN / INF rows, against the oracle and against the fragment-load kernel bit for bit."""
+    import os
+    N, D, K = case
+    rng = np.random.default_rng(N + D + K)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    X[3, 1] = np.nan
+    X[N - 1, D - 1] = np.inf
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    idx, dist = ctx.assign(X)
+    assert ctx.last_kernel == "mfma_euclid_lds_staged"
+    o = oracle.assign(X, W, threads=8)
+    rep = parity.compare(idx, dist, *o)
+    assert rep.ok, str(rep)
+    assert idx[3] == 0 and np.isinf(dist[3]) and idx[N - 1] == 0 and np.isinf(dist[N - 1])
+    ctx.set_labels(cls)
+    got = ctx.assign_matched(X, y)
+    for matching, j, d in ((True, got[0], got[1]), (False, got[2], got[3])):
+        rep = parity.compare(j, d, *oracle.assign(X, W, proto_cls=cls, labels=y, matching=matching, threads=8))
+        assert rep.ok, f"matching={matching}: {rep}"
+    os.environ["VQHIP_NO_STAGED"] = "1"                      # same model on the fragment-load kernel
+    try:
+        ctx.set_prototypes(W)
+        idx2, dist2 = ctx.assign(X)
+        assert ctx.last_kernel == "mfma_euclid_lds_pipe"
+    finally:
+        del os.environ["VQHIP_NO_STAGED"]
+    assert (idx2 == idx).all() and (dist2.view(np.uint32) == dist.view(np.uint32)).all()

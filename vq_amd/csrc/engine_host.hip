@@ -96,6 +96,14 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
                 m.samples_per_batch = 32;
                 m.launch = resident_pipe_launcher(R1, variant_env() == 31);
                 m.name = "mfma_euclid_lds_pipe";
+                // few prototypes: the search is short, the memory pipe binds, rows are staged through LDS
+                size_t staging = 0;
+                const LaunchFn staged = resident_staged_launcher(R1, &staging);
+                if (staged && res_tiles(m.K) <= 2 && (size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES + staging <= (size_t)RES_BYTES &&
+                    variant_env() != 31 && !getenv("VQHIP_NO_STAGED")) {
+                    m.launch = staged;
+                    m.name = "mfma_euclid_lds_staged";
+                }
             }
         }
     }

@@ -131,10 +131,27 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 // ------------------------------------------------------------------------------ pipelined resident kernel
 // One wave = one tile of 32 samples per batch.  D == R (host checks); a.res_tiles tiles of 32
 // prototypes are searched (search_tiles).  a.ss_limit: ||x||^2 below which no score can overflow.
-template <int R, bool MATCHED, bool DIAG = false, int NW = 8>
+//
+// STAGED (few prototypes: the image leaves room in LDS for 32 rows per wave).  With the search this short
+// the kernel is bound by the memory pipe, and the fragment-shaped loads are what it chokes on: every
+// buffer_load_dwordx4 takes 32 bytes out of each of 32 rows, 32 cache lines per instruction and every line
+// four times (measured: ~230 cycles per instruction and CU, 2.7 TB/s).  Here the next batch's rows come in
+// as whole 1 KiB pieces of the matrix (8 full lines per instruction) by LDS-DMA into the wave's staging
+// buffer, a batch ahead, and are read out as fragments from there at the top of their batch.
+template <int R>
+struct Staging {
+    static constexpr int ROWS_PER_PIECE = 256 / R;                    // rows in 1 KiB
+    static constexpr int PIECES = 32 / ROWS_PER_PIECE;
+    static constexpr int PIECE_STRIDE = 1024 + 32;                    // pad: consecutive pieces start 2 bank slots apart
+    static constexpr int BYTES = PIECES * PIECE_STRIDE;               // per wave
+    __host__ __device__ static constexpr int row_off(int r) { return (r / ROWS_PER_PIECE) * PIECE_STRIDE + (r % ROWS_PER_PIECE) * R * 4; }
+};
+
+template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
 {
     using Gm = Geom<R>;
+    using St = Staging<R>;
     unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = 0;
     auto lap = [&](int slot) {                        // diagnostic build only
         if (DIAG) {
@@ -213,12 +230,22 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         const uint64_t left = (a.N - first) * unit;
         return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
     };
+    // STAGED: this wave's 32-row staging buffer behind the image
+    char *stage = smem + ntiles * Gm::TILE_BYTES + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * St::BYTES;
     auto fetch = [&](uint64_t bb) {
         const __amdgpu_buffer_rsrc_t rx =
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
+        if constexpr (STAGED) {
+            // lane l of piece p: bytes [1024 p + 16 l, + 16) of the batch; out-of-range lanes deliver zeros
 #pragma unroll
-        for (int j = 0; j < R / 8; ++j)
-            xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+            for (int p = 0; p < St::PIECES; ++p)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void *)(stage + p * St::PIECE_STRIDE), 16,
+                                                         lane * 16, p * 1024, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j)
+                xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+        }
         if (MATCHED) {
             const __amdgpu_buffer_rsrc_t ry =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
@@ -236,6 +263,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         f32x4 xf[R / 8];
         using f32x2 = __attribute__((ext_vector_type(2))) float;
         f32x2 ss2 = {0.0f, 0.0f};
+        if constexpr (STAGED) {
+            // everything older than the stores of the previous batch has landed, the pieces among it; the
+            // fragments are out of the buffer (lgkmcnt) before the next batch's pieces are sent into it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char *rowp = stage + St::row_off(s_col) + h * 16;
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) xn[j] = *(const f32x4 *)(rowp + 32 * j);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int j = 0; j < R / 8; ++j) {
             xf[j] = xn[j];
@@ -307,6 +343,20 @@ hipError_t launch_resident(const EngineArgs &a, bool matched, hipStream_t st)
     return hipGetLastError();
 }
 
+template <int R>
+hipError_t launch_resident_staged(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
 template <int R, bool DIAG>
 hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t st)
 {
@@ -335,6 +385,16 @@ LaunchFn resident_launcher(int R, int *samples_per_batch)
     case 32: return &launch_resident<32, S>;
     case 64: return &launch_resident<64, S>;
     case 128: return &launch_resident<128, S>;
+    default: return nullptr;
+    }
+}
+
+LaunchFn resident_staged_launcher(int R, size_t *staging_bytes)
+{
+    switch (R) {
+    case 32: *staging_bytes = 8 * Staging<32>::BYTES; return &launch_resident_staged<32>;
+    case 64: *staging_bytes = 8 * Staging<64>::BYTES; return &launch_resident_staged<64>;
+    case 128: *staging_bytes = 8 * Staging<128>::BYTES; return &launch_resident_staged<128>;
     default: return nullptr;
     }
 }
