@@ -362,7 +362,7 @@ hipError_t launch_t(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t cap = 256ull * WPS;                                // 256 CUs x workgroups per CU
     const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS>), dim3(grid), dim3(256), 0, st, a);

@@ -49,30 +49,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
     const float *img = (const float *)smem;
     const float *om = (const float *)(smem + p_bytes) + n16 * ROWF + kg * 4;   // this lane's Omega row and k group
 
-    // batch queue: as in k_resident_pipe
+    // blocks of BLOCK batches per wave: the first fixed, the others claimed a block ahead (BlockQueue)
     constexpr uint32_t BLOCK = 2;
-    uint32_t pending = 0u;
-    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-    auto request = [&]() {
-        uint32_t fresh;
-        if (lane == 0)
-            fresh = __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending = fresh;
-    };
-#pragma clang diagnostic pop
+    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
-    uint32_t in_block = 0;
-    request();
+    uint32_t in_block = 0;                             // position of b inside the current block
+    queue.request();
+    // the batch after (block0, in_block)
     auto successor = [&](uint64_t &nb0, uint32_t &nin) {
         if (in_block + 1 < BLOCK) {
             nb0 = block0;
             nin = in_block + 1;
         } else {
-            uint32_t p = pending;
-            asm volatile("" : "+v"(p));
-            nb0 = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);   // added here: a VALU use next to the atomic would wait for it there
+            nb0 = queue.take();
             nin = 0;
         }
     };
@@ -105,7 +94,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
     uint64_t b = block0;
     fetch(b);
 
-    while (b < a.nbatches) {
+    while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
         uint64_t nb0;
         uint32_t nin;
         successor(nb0, nin);
@@ -130,7 +119,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
         // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
         asm volatile("" ::: "memory");
-        if (nin == 0) request();
+        if (nin == 0) queue.request();
         fetch(bnext);
 
         // ---- 16x16 accumulators -> B fragment of the 32x32x2 search: lane (s, h) gets y[8h .. 8h+7] of sample s
@@ -226,30 +215,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, i * 1024, 0));
     };
 
-    // batch queue: as in k_resident_pipe
+    // blocks of BLOCK batches per wave: the first fixed, the others claimed a block ahead (BlockQueue)
     constexpr uint32_t BLOCK = 2;
-    uint32_t pending = 0u;
-    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-    auto request = [&]() {
-        uint32_t fresh;
-        if (lane == 0)
-            fresh = __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending = fresh;
-    };
-#pragma clang diagnostic pop
+    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
-    uint32_t in_block = 0;
-    request();
+    uint32_t in_block = 0;                             // position of b inside the current block
+    queue.request();
+    // the batch after (block0, in_block)
     auto successor = [&](uint64_t &nb0, uint32_t &nin) {
         if (in_block + 1 < BLOCK) {
             nb0 = block0;
             nin = in_block + 1;
         } else {
-            uint32_t p = pending;
-            asm volatile("" : "+v"(p));
-            nb0 = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);   // added here: a VALU use next to the atomic would wait for it there
+            nb0 = queue.take();
             nin = 0;
         }
     };
@@ -278,7 +256,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     uint64_t b = block0;
     fetch(b);
 
-    while (b < a.nbatches) {
+    while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
         uint64_t nb0;
         uint32_t nin;
         successor(nb0, nin);
@@ -311,7 +289,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
         // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
         asm volatile("" ::: "memory");
-        if (nin == 0) request();
+        if (nin == 0) queue.request();
         fetch(bnext);
 
         float ss = 0.0f;
@@ -357,7 +335,7 @@ hipError_t launch_lowrank(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_lowrank_pipe<R1, true>), dim3(grid), dim3(512), 0, st, a);
@@ -371,7 +349,7 @@ hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_omega_pipe<R, true>), dim3(grid), dim3(512), 0, st, a);

@@ -52,21 +52,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
     }
     const float *img = (const float *)smem;
 
-    // blocks of SETS batches: a wave's first block is fixed, the others are claimed from the queue one
-    // block ahead of use (the returning atomic is issued a block before its value is needed)
-    uint32_t pending = 0u;
-    const uint32_t first_dynamic = gridDim.x * NW * SETS;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-    auto request = [&]() {
-        uint32_t fresh;                                // deliberately undefined off lane 0 (see k_resident_pipe)
-        if (lane == 0)
-            fresh = __hip_atomic_fetch_add(a.queue, (uint32_t)SETS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending = fresh;
-    };
-#pragma clang diagnostic pop
+    // blocks of SETS batches: the first fixed, the others claimed a block ahead (BlockQueue, mfma_device.h)
+    BlockQueue<SETS> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
     uint64_t blk = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * SETS;
-    request();
+    queue.request();
 
     const uint32_t row_bytes = R * 4u;
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
@@ -113,7 +102,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
             // the claim for the block after next goes out once this block's rows have been waited for
             if (claim && t == 0) {
                 asm volatile("" ::: "memory");
-                request();
+                queue.request();
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -127,9 +116,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
     };
 
     while (blk < a.nbatches) {
-        uint32_t p = pending;
-        asm volatile("" : "+v"(p));                    // keeps the broadcast (and the wait for the atomic) here
-        const uint64_t nblk = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+        const uint64_t nblk = queue.take();
         static_for<0, SETS>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
             project_batch(x[q], blk + q, q == 0);
@@ -155,7 +142,7 @@ hipError_t launch_project_t(const ProjectArgs &a, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_project<R>), dim3(grid), dim3(512), 0, st, a);
     return hipGetLastError();

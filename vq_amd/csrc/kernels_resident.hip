@@ -184,36 +184,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         r_begin = __builtin_amdgcn_s_memrealtime();
     }
 
-    // Batches are claimed, BLOCK at a time, by each wave from one global counter (zeroed before the
-    // launch).  Static ownership fails twice here: the older wave of a SIMD wins the arbitration for the
-    // matrix pipe, so equal shares leave the younger one alone with a quarter of its batches after its
-    // partner has exited; and when another kernel (the RCCL gather of the previous chunk) holds some CUs
-    // at launch, the workgroups that start late would still own a full share.  The returning atomic for
-    // the next block is issued two batches before its value is needed.
+    // blocks of BLOCK batches per wave: the first fixed, the others claimed a block ahead (BlockQueue)
     constexpr uint32_t BLOCK = 2;
-    uint32_t pending = 0u;                             // lane 0: first batch of the next block (in flight)
-    const uint32_t first_dynamic = gridDim.x * NW * BLOCK;     // every wave's first block is fixed
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-    auto request = [&]() {
-        uint32_t fresh;                                // deliberately undefined off lane 0: no merge copy, so the
-        if (lane == 0)                                 // compiler's wait for the atomic lands at the first use
-            fresh = __hip_atomic_fetch_add(a.queue, BLOCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pending = fresh;
-    };
-#pragma clang diagnostic pop
+    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     uint32_t in_block = 0;                             // position of b inside the current block
-    request();
+    queue.request();
     // the batch after (block0, in_block)
     auto successor = [&](uint64_t &nb0, uint32_t &nin) {
         if (in_block + 1 < BLOCK) {
             nb0 = block0;
             nin = in_block + 1;
         } else {
-            uint32_t p = pending;
-            asm volatile("" : "+v"(p));                // keeps the broadcast (and the wait for the atomic) here
-            nb0 = first_dynamic + (uint32_t)__builtin_amdgcn_readfirstlane((int)p);   // added here: a VALU use next to the atomic would wait for it there
+            nb0 = queue.take();
             nin = 0;
         }
     };
@@ -255,7 +238,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     uint64_t b = block0;
     fetch(b);
 
-    while (b < a.nbatches) {
+    while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
         uint64_t nb0;
         uint32_t nin;
         successor(nb0, nin);
@@ -288,7 +271,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         // vmcnt counts in issue order: the atomic goes out only after this batch's rows have been waited
         // for, or that wait would include the atomic's own round trip
         asm volatile("" ::: "memory");
-        if (nin == 0) request();                       // the block after the one just taken
+        if (nin == 0) queue.request();                       // the block after the one just taken
         fetch(bnext);
         lap(1);                                        // 1: issue of the next batch's loads
 
@@ -348,7 +331,7 @@ hipError_t launch_resident_staged(const EngineArgs &a, bool matched, hipStream_t
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
@@ -362,7 +345,7 @@ hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t s
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(uint32_t), st);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if (DIAG && getenv("VQHIP_NW4"))
         hipLaunchKernelGGL((k_resident_pipe<R, false, true, 4>), dim3(grid), dim3(256), 0, st, a);

@@ -140,6 +140,55 @@ __device__ __forceinline__ void settle_ties(const EngineArgs &a, uint32_t label,
     if (MATCHED && wn.d < INFINITY) wn.i = lowest(wn.i, false);
 }
 
+// ------------------------------------------------------------------------------ batch queue of the wave-per-batch kernels
+// Every wave works through blocks of BLOCK consecutive batches of 32 samples.  Its first block is fixed (its
+// wave number); the others are claimed from counters in global memory, zeroed before the launch.
+//   * Dynamic, because static ownership fails twice: the older wave of a SIMD wins the arbitration for the
+//     matrix pipe, so equal shares leave the younger one alone at the end; and when another kernel (the RCCL
+//     gather of the previous chunk) holds some CUs at launch, late workgroups would still own a full share.
+//   * QUEUE_GROUPS counters, not one: returning device-scope atomics on one address complete at about 80 per
+//     microsecond on MI355X, and short batches (few prototypes) need more -- one counter capped every such
+//     launch at 2.7 TB/s, whatever its loads looked like.  Wave w starts on counter w % GROUPS; claim v of
+//     counter g is block nwaves + v * GROUPS + g.  A wave whose counter runs dry walks the others.
+//   * One block ahead: the atomic for the block after next is issued when a block is taken, and its result is
+//     first touched by the broadcast that needs it (nothing next to the atomic may use it: the compiler would
+//     wait for the round trip there).
+template <uint32_t BLOCK>
+struct BlockQueue {
+    uint32_t *ctr;
+    uint32_t group, first_dynamic, pending;
+    uint64_t nblocks;
+    int lane;
+    __device__ __forceinline__ BlockQueue(uint32_t *counters, int lane_, uint32_t wave_id, uint32_t nwaves, uint64_t nbatches)
+        : ctr(counters), group(wave_id % QUEUE_GROUPS), first_dynamic(nwaves), pending(0u),
+          nblocks((nbatches + BLOCK - 1) / BLOCK), lane(lane_) {}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+    __device__ __forceinline__ void request()
+    {
+        uint32_t fresh;                                // deliberately undefined off lane 0: no merge copy, so the
+        if (lane == 0)                                 // compiler's wait for the atomic lands at the first use
+            fresh = __hip_atomic_fetch_add(ctr + group * QUEUE_GROUP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pending = fresh;
+    }
+#pragma clang diagnostic pop
+    __device__ __forceinline__ uint64_t block_of(uint32_t claim) const { return first_dynamic + (uint64_t)claim * QUEUE_GROUPS + group; }
+    // First batch of the block claimed by the last request() (wave-uniform); >= nbatches when nothing is left.
+    __device__ __forceinline__ uint64_t take()
+    {
+        uint32_t p = pending;
+        asm volatile("" : "+v"(p));                    // keeps the broadcast (and the wait for the atomic) here
+        uint64_t id = block_of((uint32_t)__builtin_amdgcn_readfirstlane((int)p));
+        for (uint32_t tries = 1; tries < QUEUE_GROUPS && id >= nblocks; ++tries) {     // the end of a launch only
+            group = (group + 1) % QUEUE_GROUPS;
+            uint32_t v = 0u;
+            if (lane == 0) v = __hip_atomic_fetch_add(ctr + group * QUEUE_GROUP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            id = block_of((uint32_t)__builtin_amdgcn_readfirstlane((int)v));
+        }
+        return id * BLOCK;
+    }
+};
+
 // ---- packed screening keys (what they are and why: the comment above k_resident_pipe)
 // Keys are f32 bit patterns and are compared AS FLOATS (v_min_f32 / v_med3_f32), so a score may have
 // either sign and the accumulators start at the plain ||w_k||^2 column.  Nothing that is screened may be

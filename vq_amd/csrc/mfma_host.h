@@ -23,6 +23,11 @@ LaunchFn resident_staged_launcher(int R, size_t *staging_bytes);
 LaunchFn omega_pipe_launcher(int R);                                             // kernels_omega.hip: k_omega_pipe
 LaunchFn lowrank_launcher(int R1);                                               // kernels_omega.hip: k_lowrank_pipe
 
+// batch counters of one launch (BlockQueue, mfma_device.h): QUEUE_GROUPS counters, 4 KiB apart
+constexpr uint32_t QUEUE_GROUPS = 16;
+constexpr uint32_t QUEUE_GROUP_STRIDE = 1024;                                    // in u32
+constexpr size_t QUEUE_BYTES = (size_t)QUEUE_GROUPS * QUEUE_GROUP_STRIDE * sizeof(uint32_t);
+
 constexpr int RES_BYTES = 156 * 1024;       // LDS one resident workgroup may fill with images
 constexpr float PAD_SCORE = 3.0e38f;        // accumulator init of pad rows: finite, above every real score
 

@@ -8,13 +8,15 @@
 #include <vector>
 
 #include "engine.h"
+#include "mfma_host.h"
 
 namespace vq {
 
 // Batch counters, one per launch in flight: launches of one model on different streams (the two staging
 // streams of the host path) may overlap at their edges, and a launch that zeroed the counter of the one
 // still running would hand its batches to it.  Slots are used round-robin.
-constexpr uint32_t QUEUE_SLOTS = 16, QUEUE_STRIDE = 16;     // 16 counters, 64 bytes apart
+constexpr uint32_t QUEUE_SLOTS = 16;                                  // sets of counters (mfma_host.h: QUEUE_BYTES each)
+constexpr uint32_t QUEUE_STRIDE = QUEUE_GROUPS * QUEUE_GROUP_STRIDE;  // u32 between sets
 
 // Tile images for `nrows` weight rows of length `len` (zero padded to R), scaled by `scale`;
 // init[r] / cls[r] fill the tail; pad rows get (0 weights, pad_init, cls 0xFFFFFFFF).
