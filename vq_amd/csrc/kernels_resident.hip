@@ -188,25 +188,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     constexpr uint32_t BLOCK = 2;
     BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
-    uint32_t in_block = 0;                             // position of b inside the current block
     queue.request();
-    // the batch after (block0, in_block)
-    auto successor = [&](uint64_t &nb0, uint32_t &nin) {
-        if (in_block + 1 < BLOCK) {
-            nb0 = block0;
-            nin = in_block + 1;
-        } else {
-            nb0 = queue.take();
-            nin = 0;
-        }
-    };
     // Rows come in through a buffer descriptor rebased per batch (wave-uniform, so the 4 GiB offset
     // range is per batch, not per matrix): rows past N read as zeros by the hardware range check, one
     // per-lane offset serves every chunk (immediate offsets), and nothing needs a 64-bit address.
+    // One register set per batch of the block: a set is refilled (for the same position of the next block)
+    // right after its batch's epilogue and has the other batch's whole search to land -- no copies between sets.
     const uint32_t row_bytes = a.D * 4u;
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
-    f32x4 xn[R / 8];                                   // rows of the next batch, in flight
-    uint32_t ln = 0u;
+    constexpr int SETS = STAGED ? 1 : (int)BLOCK;      // STAGED: the rows wait in LDS, one register set serves
+    f32x4 x[SETS][R / 8];
+    uint32_t ln[BLOCK];
+#pragma unroll
+    for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
     auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {      // bytes from row bb*32 to the end, clamped
         const uint64_t first = bb * 32;
         if (first >= a.N) return 0u;
@@ -215,7 +209,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     };
     // STAGED: this wave's 32-row staging buffer behind the image
     char *stage = smem + ntiles * Gm::TILE_BYTES + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * St::BYTES;
-    auto fetch = [&](uint64_t bb) {
+    // rows (and labels) of batch bb -> register set / label slot q, or -> the staging buffer
+    auto fetch = [&](auto qq, uint64_t bb) {
+        constexpr int q = decltype(qq)::value;
         const __amdgpu_buffer_rsrc_t rx =
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
         if constexpr (STAGED) {
@@ -227,80 +223,88 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         } else {
 #pragma unroll
             for (int j = 0; j < R / 8; ++j)
-                xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+                x[q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
         }
         if (MATCHED) {
             const __amdgpu_buffer_rsrc_t ry =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
-            ln = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+            ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
         }
     };
-    uint64_t b = block0;
-    fetch(b);
+    if constexpr (STAGED) {
+        fetch(std::integral_constant<int, 0>{}, block0);
+    } else {
+        static_for<0, (int)BLOCK>([&](auto qq) { fetch(qq, block0 + decltype(qq)::value); });
+    }
 
     while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
-        uint64_t nb0;
-        uint32_t nin;
-        successor(nb0, nin);
-        const uint64_t bnext = nb0 + nin;
-        f32x4 xf[R / 8];
-        using f32x2 = __attribute__((ext_vector_type(2))) float;
-        f32x2 ss2 = {0.0f, 0.0f};
-        if constexpr (STAGED) {
-            // everything older than the stores of the previous batch has landed, the pieces among it; the
-            // fragments are out of the buffer (lgkmcnt) before the next batch's pieces are sent into it
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const char *rowp = stage + St::row_off(s_col) + h * 16;
+        const uint64_t nb0 = queue.take();             // first batch of the next block (the wait for its atomic is here)
+        static_for<0, (int)BLOCK>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            constexpr int set = STAGED ? 0 : q;
+            const uint64_t b = block0 + q;
+            f32x4(&xf)[R / 8] = x[set];
+            using f32x2 = __attribute__((ext_vector_type(2))) float;
+            f32x2 ss2 = {0.0f, 0.0f};
+            if constexpr (STAGED) {
+                // everything older than the stores of the previous batch has landed, the pieces among it; the
+                // fragments are out of the buffer (lgkmcnt) before the next batch's pieces are sent into it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const char *rowp = stage + St::row_off(s_col) + h * 16;
 #pragma unroll
-            for (int j = 0; j < R / 8; ++j) xn[j] = *(const f32x4 *)(rowp + 32 * j);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int j = 0; j < R / 8; ++j) {
-            xf[j] = xn[j];
-            const f32x2 lo = {xf[j][0], xf[j][1]}, hi = {xf[j][2], xf[j][3]};
-            ss2 = __builtin_elementwise_fma(lo, lo, ss2);
-            ss2 = __builtin_elementwise_fma(hi, hi, ss2);
-        }
-        const uint32_t label = ln;
-        float ss = ss2[0] + ss2[1];
-        ss += xor32(ss);                               // ||x||^2, the same value in both lanes of the pair
-        const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge rows: exact scan at the end
-        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
-        lap(0);                                        // 0: delivery of this batch's rows
-        // vmcnt counts in issue order: the atomic goes out only after this batch's rows have been waited
-        // for, or that wait would include the atomic's own round trip
-        asm volatile("" ::: "memory");
-        if (nin == 0) queue.request();                       // the block after the one just taken
-        fetch(bnext);
-        lap(1);                                        // 1: issue of the next batch's loads
-
-        Keys2 ku;
-        KeysM km;
-        search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
-        lap(2);                                        // 2: tile loop
-
-        Best1 wp, wn;
-        finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
-        settle_ties<MATCHED>(a, label, wp, wn);
-        {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
-            const int rec = (int)records(b, 4u);
-            const uint32_t so = (uint32_t)s_col * 4u;
-            auto put = [&](void *base, uint32_t bits) {
-                __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
-            };
-            if (h == 0) {
-                if (a.out.idx) put(a.out.idx + b * 32, wp.i);
-                if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
-            } else {
-                if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
-                if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+                for (int j = 0; j < R / 8; ++j) xf[j] = *(const f32x4 *)(rowp + 32 * j);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-        }
-        lap(3);                                        // 3: batch epilogue
-        b = bnext;
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) {
+                const f32x2 lo = {xf[j][0], xf[j][1]}, hi = {xf[j][2], xf[j][3]};
+                ss2 = __builtin_elementwise_fma(lo, lo, ss2);
+                ss2 = __builtin_elementwise_fma(hi, hi, ss2);
+            }
+            const uint32_t label = ln[q];
+            float ss = ss2[0] + ss2[1];
+            ss += xor32(ss);                           // ||x||^2, the same value in both lanes of the pair
+            const bool unsafe = !(ss < a.ss_limit);    // NaN / INF / huge rows: exact scan at the end
+            const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+            lap(0);                                    // 0: delivery of this batch's rows
+            // vmcnt counts in issue order: the atomic goes out only after this batch's rows have been waited
+            // for, or that wait would include the atomic's own round trip
+            asm volatile("" ::: "memory");
+            if constexpr (q == 0) queue.request();     // the block after the one just taken
+            // the staging buffer is free again; the label goes to the slot of the batch it belongs to
+            if constexpr (STAGED) fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
+            lap(1);                                    // 1: issue of the claim / of the staged variant's next pieces
+
+            Keys2 ku;
+            KeysM km;
+            search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
+            lap(2);                                    // 2: tile loop
+
+            Best1 wp, wn;
+            finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+            settle_ties<MATCHED>(a, label, wp, wn);
+            {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
+                const int rec = (int)records(b, 4u);
+                const uint32_t so = (uint32_t)s_col * 4u;
+                auto put = [&](void *base, uint32_t bits) {
+                    __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+                };
+                if (h == 0) {
+                    if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                    if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+                } else {
+                    if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                    if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+                }
+            }
+            // this set's rows are dead: refill it for the same position of the next block
+            if constexpr (!STAGED) {
+                asm volatile("" ::: "memory");
+                fetch(qq, nb0 + q);
+            }
+            lap(3);                                    // 3: batch epilogue (+ issue of the refill)
+        });
         block0 = nb0;
-        in_block = nin;
     }
     if (DIAG && a.dbg && lane == 0) {
         unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
