@@ -94,12 +94,12 @@ SHAPES = [
 ]
 
 
-# kernel family VQHIP_KERNEL_AUTO must pick per shape (the engine serves D % 4 == 0, D <= 256)
+# kernel family VQHIP_KERNEL_AUTO must pick per shape (the MFMA kernels serve every D <= 256)
 AUTO_KERNEL = {
     "c1_vq_iris_shape": "mfma_euclid", "glvq_128x256": "mfma_euclid", "glvq_ragged_d100_k37": "mfma_euclid",
     "glvq_d64_k70": "mfma_euclid", "glvq_streamed_k600": "mfma_euclid", "glvq_streamed_d256": "mfma_euclid", "gmlvq_128x128": "mfma_omega", "gmlvq_small_d12": "mfma_omega",
     "liramlvq_r16_d256": "mfma_omega", "liramlvq_r3_d20": "mfma_omega", "lgmlvq_8x128": "mfma_local",
-    "lgmlvq_small": "scalar",      # D = 10 is not a multiple of 4
+    "lgmlvq_small": "mfma_local",  # D = 10: rows only 4-byte aligned, cut at D inside the kernel
 }
 
 
@@ -262,8 +262,8 @@ def test_host_path_multi_chunk(ctx):
 def test_host_path_multi_chunk_shared_scratch_and_queues(ctx):
     """Chunks alternate between two streams: the scalar Omega path shares one projection scratch buffer
     between them, the MFMA kernels one set of batch counters.  Every chunk must come out whole."""
-    m = _model(("t", "LiRaMLVQ", 1, 10, 6, 3, "global"))              # D = 10: scalar kernels, 3.3M-row chunks
-    N = (128 << 20) // 40 * 2 + 4321
+    m = _model(("t", "LiRaMLVQ", 1, 300, 6, 3, "global"))             # D = 300 > 256: scalar kernels, 111K-row chunks
+    N = (128 << 20) // 1200 * 2 + 4321
     X = synth.samples_host(m, 0, N)
     ctx.set_kernel_policy(KERNEL_AUTO)
     synth.load_model(ctx, m, with_labels=False)
@@ -688,3 +688,33 @@ def test_staged_kernel(ctx, case):
     finally:
         del os.environ["VQHIP_NO_STAGED"]
     assert (idx2 == idx).all() and (dist2.view(np.uint32) == dist.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("D", [1, 2, 3, 5, 10, 30, 63, 101, 126, 255])
+def test_row_lengths_that_are_not_multiples_of_four(ctx, D):
+    """Rows of any length up to 256 run on the MFMA kernels: 16-byte fetches from 4-byte aligned rows, cut at D
+    (the values behind a row are the next row's -- here NaN / INF poisoned on purpose -- or the end of the buffer)."""
+    rng = np.random.default_rng(D)
+    N, K = 3001, 37
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    X[1::2, 0] = np.nan                        # every second row starts with a NaN: its neighbours must not see it
+    X[4::8, :] = np.inf
+    clean = np.isfinite(X).all(axis=1)
+    o = oracle.assign(X, W, threads=8)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    idx, dist = ctx.assign(X)
+    assert ctx.last_kernel.startswith("mfma_euclid"), ctx.last_kernel
+    rep = parity.compare(idx, dist, *o)
+    assert rep.ok, str(rep)
+    assert np.isfinite(dist[clean]).all() and (idx[~clean] == 0).all() and np.isinf(dist[~clean]).all()
+    if D >= 3:
+        M = 3
+        Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+        Xc = X[clean]
+        ctx.set_omega(Om)
+        idx, dist = ctx.assign(Xc)
+        assert ctx.last_kernel.startswith("mfma_omega"), ctx.last_kernel
+        rep = parity.compare(idx, dist, *oracle.assign(Xc, W, omega=Om, threads=8), atol=2e-6)
+        assert rep.ok, str(rep)

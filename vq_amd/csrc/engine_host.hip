@@ -114,7 +114,9 @@ template <int R1, int R2>
 bool bind_omega(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
                 const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
 {
-    if (m.R1 != (uint32_t)R1 || m.R2 != (uint32_t)R2) return false;
+    if (m.R1 != (uint32_t)R1 || m.R2 > (uint32_t)R2) return false;     // fewer Omega rows than R2: zero padded
+    m.R2 = R2;
+    m.ldp = R2;
     img1 = build_images<R1>(Om.data(), m.M, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, m.ngroups1, R2 >= 32 ? R2 : 32);
     img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
                             m.ngroups2);
@@ -160,11 +162,13 @@ template <int R>
 bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
                      const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
 {
-    if (m.D != (uint32_t)R || m.R2 != (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;
+    if (m.D != (uint32_t)R || m.R2 > (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;   // Omega zero padded to R rows
+    if ((size_t)res_tiles(m.K) * Geom<R>::TILE_BYTES > (size_t)RES_BYTES) return false;
+    m.R2 = R;
+    m.ldp = R;
     uint32_t ngroups2 = 0;
     std::vector<float> pimg = build_images<R>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(),
                                               PAD_SCORE, ngroups2);
-    if ((size_t)res_tiles(m.K) * Geom<R>::TILE_BYTES > (size_t)RES_BYTES) return false;
     img2 = std::move(pimg);
     m.ngroups2 = ngroups2;
     // Omega as A-fragment pieces: piece (t, j), lane (row, h) = Omega[32 t + row][4 (2 j + h) .. + 3]
@@ -214,8 +218,8 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                           hipError_t &herr)
 {
     herr = hipSuccess;
-    if (D % 4 != 0 || D > 256) {
-        why = "sample length must be a multiple of 4 and at most 256";
+    if (D > 256) {
+        why = "sample length above 256";
         return nullptr;
     }
     if (omega_kind != OMEGA_NONE && M > 256) {
@@ -276,9 +280,11 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                  bind_lowrank<64>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<32>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega_pipe<128>(m, img1, img2, Om, P, norms, cls) || bind_omega_pipe<64>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega_pipe<32>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
+                 // streamed engine: per R1 the narrowest instantiated search width that holds Omega's rows
                  bind_omega<16, 16>(m, img1, img2, Om, P, norms, cls) || bind_omega<32, 16>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega<32, 32>(m, img1, img2, Om, P, norms, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, norms, cls);
+                 bind_omega<32, 32>(m, img1, img2, Om, P, norms, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega<256, 64>(m, img1, img2, Om, P, norms, cls);
         }
         // zero-padded plain rows for the exact re-measurement
         plain.assign((size_t)K * m.ldp, 0.0f);

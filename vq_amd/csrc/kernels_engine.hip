@@ -47,7 +47,6 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const uint32_t ngroups = MODE == MODE_OMEGA ? NG1 + a.ngroups2 : a.ngroups1;
-    const uint32_t Cact = a.D >> 2;
 
     // DMA source of stage q of the cyclic weight stream
     auto issue = [&](uint32_t q, int buf) {
@@ -92,12 +91,11 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
     // D < R1: the chunks past the row's end hold the next row's values (or range-check zeros); the weight
     // images are zero there, but 0 x INF is NaN, so they are cleared before the rows are used
     auto mask_columns = [&]() {
-        if (Cact < (uint32_t)(R1 / 4)) {
+        if (a.D < (uint32_t)R1) {
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int j = 0; j < R1 / 8; ++j)
-                    if ((uint32_t)(2 * j + h) >= Cact) xf[s][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < R1 / 8; ++j) xf[s][j] = mask_chunk(xf[s][j], (uint32_t)(2 * j + h), a.D);
         }
     };
 
@@ -390,6 +388,7 @@ LaunchFn streamed_launcher(int mode, int R1, int R2, int *spb)
            pick<MODE_OMEGA, 128, 128, 1>(mode, R1, R2, fn, spb) || pick<MODE_OMEGA, 256, 16, 1>(mode, R1, R2, fn, spb) ||
            pick<MODE_OMEGA, 16, 16, 1>(mode, R1, R2, fn, spb) || pick<MODE_OMEGA, 32, 16, 1>(mode, R1, R2, fn, spb) ||
            pick<MODE_OMEGA, 32, 32, 1>(mode, R1, R2, fn, spb) || pick<MODE_OMEGA, 64, 64, 1>(mode, R1, R2, fn, spb) ||
+           pick<MODE_OMEGA, 256, 64, 1>(mode, R1, R2, fn, spb) ||
            pick<MODE_LOCAL, 16, 16, 2>(mode, R1, R2, fn, spb) || pick<MODE_LOCAL, 32, 32, 2>(mode, R1, R2, fn, spb) ||
            pick<MODE_LOCAL, 64, 64, 2>(mode, R1, R2, fn, spb) || pick<MODE_LOCAL, 128, 128, 2>(mode, R1, R2, fn, spb) ||
            pick<MODE_LOCAL, 256, 256, 1>(mode, R1, R2, fn, spb));

@@ -16,7 +16,8 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const uint32_t ntiles = a.res_tiles;
-    const uint32_t Cact = a.D >> 2;
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
 
     {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
         const uint32_t bytes = ntiles * Gm::TILE_BYTES;
@@ -37,17 +38,26 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
         uint32_t label[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            sample[s] = (b * S + s) * 32 + s_col;
-            const bool live = sample[s] < a.N;
-            const float *xrow = a.X + sample[s] * a.D;
-#pragma unroll
-            for (int j = 0; j < R / 8; ++j) {
-                const uint32_t c = 2 * j + h;
-                const bool ok = live && c < Cact;
-                const f32x4 v = *(const f32x4 *)(ok ? xrow + 4 * c : a.X);
-                xf[s][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            // rows through a buffer descriptor rebased per tile: rows past N read as zeros, rows of any length
+            // (4-byte aligned) are fetched 16 bytes at a time and cut at D
+            const uint64_t first = (b * S + s) * 32;
+            sample[s] = first + s_col;
+            uint32_t rec = 0u, rec_y = 0u;
+            if (first < a.N) {
+                const uint64_t left = a.N - first;
+                rec = left * row_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * row_bytes);
+                rec_y = left * 4u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * 4u);
             }
-            label[s] = (MATCHED && live) ? a.y[sample[s]] : 0u;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + first * a.D), 0, (int)rec, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j)
+                xf[s][j] = mask_chunk(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0)),
+                                      (uint32_t)(2 * j + h), a.D);
+            label[s] = 0u;
+            if (MATCHED) {
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + first), 0, (int)rec_y, 0x00020000);
+                label[s] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+            }
         }
         Top2 top[S];
         Best1 pos[S], neg[S];

@@ -20,7 +20,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 struct EngineArgs {
     const float *X;           // N x D samples (row stride D)
     uint64_t N;
-    uint32_t D;               // actual sample length (multiple of 4, <= R1)
+    uint32_t D;               // actual sample length (<= R1; any value: rows need only 4-byte alignment)
     const uint32_t *y;        // sample class ids (matched) or null
     const float *img1;        // stage-1 groups: prototypes (EUCLID), Omega rows (OMEGA), Omega_j rows (LOCAL)
     uint32_t ngroups1;
@@ -298,6 +298,16 @@ __device__ __forceinline__ bool keyless(uint32_t ak, uint32_t ai, uint32_t bk, u
 {
     const float a = __builtin_bit_cast(float, ak), b = __builtin_bit_cast(float, bk);
     return a < b || (a == b && ai < bi);
+}
+
+// Chunk c = 2j + h of a row of D floats fetched as 16 bytes: values at or past D belong to the next row (or are
+// range-check zeros).  The weight images are zero there, but 0 x INF is NaN, so they are cleared.  D need not
+// be a multiple of 4 (rows are then only 4-byte aligned, which buffer loads accept).
+__device__ __forceinline__ f32x4 mask_chunk(f32x4 v, uint32_t c, uint32_t D)
+{
+    const uint32_t first = 4u * c;
+    if (first + 4u <= D) return v;
+    return f32x4{first + 0u < D ? v[0] : 0.f, first + 1u < D ? v[1] : 0.f, first + 2u < D ? v[2] : 0.f, 0.f};
 }
 
 // LDS-DMA of one stage (BYTES, multiple of 16) from its pre-swizzled global image: a linear copy,
