@@ -718,3 +718,46 @@ def test_row_lengths_that_are_not_multiples_of_four(ctx, D):
         assert ctx.last_kernel.startswith("mfma_omega"), ctx.last_kernel
         rep = parity.compare(idx, dist, *oracle.assign(Xc, W, omega=Om, threads=8), atol=2e-6)
         assert rep.ok, str(rep)
+
+
+@pytest.mark.parametrize("case", [(2000, 300, 50), (1500, 784, 10), (700, 257, 128), (333, 1000, 33), (65, 2049, 3), (4097, 512, 64)],
+                         ids=lambda c: "n%d_d%d_k%d" % c)
+def test_long_rows(ctx, case):
+    """Rows above 256 values (k_long: the reduction in chunks of 128, candidates re-measured in a second sweep):
+    unstructured data, plain and matched, NaN / INF / huge rows inside a batch, nothing written past N."""
+    import torch
+    N, D, K = case
+    rng = np.random.default_rng(N + D + K)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 2, D)).astype(np.float32)
+    X[5 % N, D - 1] = np.nan
+    X[40 % N, 0] = np.inf
+    X[33 % N] *= np.float32(1e30)                       # ||x||^2 overflows f32: exact scan
+    o = oracle.assign(X[:N], W, threads=8)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    Xd = torch.from_numpy(X).cuda()
+    idx = torch.full((N + 2,), -7, dtype=torch.int32, device="cuda")
+    dist = torch.full((N + 2,), -7.0, dtype=torch.float32, device="cuda")
+    ctx.assign_into(Xd[:N], idx[:N], dist[:N])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "mfma_euclid_long"
+    assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()
+    gi, gd = idx[:N].cpu().numpy(), dist[:N].cpu().numpy()
+    fin = np.isfinite(gd)                                # f32 overflows where f64 does not
+    rep = parity.compare(gi[fin], gd[fin], o[0][fin], o[1][fin], o[2][fin])
+    print(case, rep)
+    assert rep.ok, str(rep)
+    assert not fin[5 % N] and gi[5 % N] == 0 and not fin[40 % N] and gi[40 % N] == 0
+    assert fin.sum() >= N - 3
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    ctx.set_labels(cls)
+    jp, dp, jn, dn = ctx.assign_matched(X[:N], y)
+    assert ctx.last_kernel == "mfma_euclid_long"
+    for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+        om = oracle.assign(X[:N], W, proto_cls=cls, labels=y, matching=matching, threads=8)
+        f2 = np.isfinite(d) | ~np.isfinite(om[1])        # rows with no eligible prototype: +INF on both sides
+        f2 &= fin | ~np.isfinite(om[1])
+        rep = parity.compare(j[f2], d[f2], om[0][f2], om[1][f2], om[2][f2])
+        assert rep.ok, f"{case} matching={matching}: {rep}"

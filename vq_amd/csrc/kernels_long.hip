@@ -1,0 +1,286 @@
+// Euclidean models with rows longer than 256 values (VQ / LVQ / GLVQ: src/helpers.rs:11-24, 55-77, 91-132) on the
+// matrix cores, for up to 128 prototypes.  The reduction runs over chunks of 128 values:
+//   pass 1  every chunk of the wave's 32 rows is fetched once and multiplied into ALL the tiles' accumulators
+//           (NT x 16 registers stay live across the chunks); the prototypes' A fragments stream from L2 through a
+//           register ring, one 1 KiB piece per (chunk, tile, step), so there is no LDS stage and no barrier;
+//   screen  packed keys over the finished scores ||w_k||^2 - 2 x.w_k, best two per lane (labelled: best per class group);
+//   pass 2  the rows are fetched again and the candidates re-measured in the direct sum (x_d - w_kd)^2 form,
+//           rooted, compared like helpers.rs:70.  The second fetch is the price of rows that fit neither the
+//           register file nor LDS; the kernel is HBM-bound at about twice the algorithmic bytes.
+#include <cstdlib>
+
+#include "mfma_device.h"
+
+namespace vq {
+
+template <int NT, bool MATCHED, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
+{
+    constexpr int NJ = 16, DEPTH = 8;                  // steps of 4 MFMAs per chunk and tile; pieces in flight
+    static_assert(NJ % DEPTH == 0, "ring slots are compile-time");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t NC = a.nchunks, npieces = NC * NT * NJ;
+
+    // A fragments: piece p = (chunk * NT + tile) * NJ + step, this lane's 16 bytes at p * 1024 + lane * 16
+    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, (int)(npieces * 1024u), 0x00020000);
+    const uint32_t om_off = (uint32_t)lane * 16u;
+    auto piece = [&](uint32_t p) {                     // past the last piece: range-check zeros, never used
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, (int)(p * 1024u), 0));
+    };
+    const float *tails = a.img2;                       // per tile: 32 x ||w_k||^2 (pad rows PAD_SCORE), 32 x class id
+
+    constexpr uint32_t BLOCK = 2;
+    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    queue.request();
+
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    f32x4 xa[NJ], xb[NJ];                              // two chunks of the rows, worked alternately
+    // chunk c of batch bb: lane (s, h) gets the 16-byte pieces 2j + h of values [128 c, 128 c + 128) of row s
+    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * 512u), 0));
+    };
+    // values at or past D (the last chunk's tail: the next row, or range-check zeros) are cleared
+    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
+        if ((c + 1u) * 128u > a.D) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * 32u + (uint32_t)(2 * j + h), a.D);
+        }
+    };
+    // fn(chunk registers, chunk number) over all chunks of batch bb; xa must hold (or be receiving) chunk 0
+    auto for_chunks = [&](uint64_t bb, auto &&fn) {
+        for (uint32_t c = 0; c < NC; c += 2) {
+            if (c + 1 < NC) fetch_x(xb, bb, c + 1);
+            cut(xa, c);
+            fn(xa, c);
+            if (c + 1 < NC) {
+                if (c + 2 < NC) fetch_x(xa, bb, c + 2);
+                cut(xb, c + 1);
+                fn(xb, c + 1);
+            }
+        }
+    };
+    // sum over this lane's part of (x - w_k)^2 for two prototypes, all chunks (rows fetched again)
+    auto exact_pair = [&](uint64_t bb, uint32_t k0, uint32_t k1, float &e0, float &e1) {
+        const float *w0 = a.plain + (size_t)k0 * a.ldp + 4 * h, *w1 = a.plain + (size_t)k1 * a.ldp + 4 * h;
+        float p0 = 0.0f, p1 = 0.0f;
+        fetch_x(xa, bb, 0);
+        for_chunks(bb, [&](const f32x4 (&xs)[NJ], uint32_t c) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const f32x4 v0 = *(const f32x4 *)(w0 + c * 128u + 8 * j), v1 = *(const f32x4 *)(w1 + c * 128u + 8 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d0 = xs[j][e] - v0[e], d1 = xs[j][e] - v1[e];
+                    p0 = fmaf(d0, d0, p0);
+                    p1 = fmaf(d1, d1, p1);
+                }
+            }
+        });
+        e0 = p0 + xor32(p0);
+        e1 = p1 + xor32(p1);
+    };
+
+    uint32_t ln[BLOCK];
+#pragma unroll
+    for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
+    auto fetch_label = [&](uint32_t q, uint64_t bb) {
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    fetch_x(xa, block0, 0);
+    fetch_label(0, block0);
+    fetch_label(1, block0 + 1);
+
+    while (block0 < a.nbatches) {
+        const uint64_t nb0 = queue.take();
+        queue.request();
+#pragma unroll
+        for (uint32_t q = 0; q < BLOCK; ++q) {
+            const uint64_t b = block0 + q;
+            const uint64_t bnext = q + 1 < BLOCK ? b + 1 : nb0;
+            const uint32_t label = ln[q];
+
+            // ---- pass 1: all tiles' scores, accumulators start at the ||w_k||^2 column
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 ci = *(const f32x4 *)(tails + t * TAIL_FLOATS + 8 * g + 4 * h);
+                    acc[t][4 * g + 0] = ci[0]; acc[t][4 * g + 1] = ci[1]; acc[t][4 * g + 2] = ci[2]; acc[t][4 * g + 3] = ci[3];
+                }
+            f32x4 ring[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = piece((uint32_t)i);
+            uint32_t pnext = DEPTH;                    // next piece to request
+            float ss = 0.0f;
+            for_chunks(b, [&](const f32x4 (&xs)[NJ], uint32_t) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ss = fmaf(xs[j][e], xs[j][e], ss);
+                static_for<0, NT>([&](auto tt) {
+                    static_for<0, NJ>([&](auto jj) {
+                        constexpr int j = decltype(jj)::value;
+                        const f32x4 av = ring[j % DEPTH];
+                        ring[j % DEPTH] = piece(pnext++);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[decltype(tt)::value] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xs[j][e], acc[decltype(tt)::value], 0, 0, 0);
+                    });
+                });
+            });
+            ss += xor32(ss);
+            bool unsafe = !(ss < a.ss_limit);          // NaN / INF / huge rows: exact scan below
+
+            // ---- screening
+            Keys2 ku;
+            KeysM km;
+            static_for<0, NT>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                if constexpr (!MATCHED) {
+                    const Keys2 before = ku;
+                    screen16<1>(acc[t], ku);
+                    settle_tiles(ku, before, (uint32_t)t);
+                } else {
+                    const KeysM before = km;
+                    const uint32_t *tcls = (const uint32_t *)(tails + t * TAIL_FLOATS) + 32 + 4 * h;
+                    asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");   // asm readers of fresh MFMA results: wait states by hand
+                    static_for<0, 16>([&](auto oo) {
+                        constexpr int o = decltype(oo)::value;
+                        const uint32_t key = pack_key(acc[t][o], o);
+                        const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;     // helpers.rs:113 / :122
+                        const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
+                        km.p = kmin(km.p, kp);
+                        km.n = kmin(km.n, kn);
+                    });
+                    km.tp = km.p != before.p ? (uint32_t)t : before.tp;
+                    km.tn = km.n != before.n ? (uint32_t)t : before.tn;
+                }
+            });
+
+            // ---- the lane pair agrees on two candidates; pass 2 re-measures them
+            uint32_t c0, c1;                           // unlabelled: best two; labelled: best matching, best non-matching
+            bool v0, v1;
+            if (!MATCHED) {
+                const uint32_t k1 = key_row(ku.b1, ku.t1, h), k2 = key_row(ku.b2, ku.t2, h);
+                const uint32_t pb1 = xor32(ku.b1), pb2 = xor32(ku.b2), pk1 = xor32(k1), pk2 = xor32(k2);
+                uint32_t f, sd;
+                if (keyless(pb1, pk1, ku.b1, k1)) {
+                    f = pb1; c0 = pk1;
+                    if (keyless(ku.b1, k1, pb2, pk2)) { sd = ku.b1; c1 = k1; } else { sd = pb2; c1 = pk2; }
+                } else {
+                    f = ku.b1; c0 = k1;
+                    if (keyless(pb1, pk1, ku.b2, k2)) { sd = pb1; c1 = pk1; } else { sd = ku.b2; c1 = k2; }
+                }
+                v0 = key_valid(f);
+                v1 = key_valid(sd);
+            } else {
+                uint32_t kp = key_row(km.p, km.tp, h), kn = key_row(km.n, km.tn, h), p = km.p, n = km.n;
+                const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
+                if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
+                if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
+                c0 = kp; c1 = kn;
+                v0 = key_valid(p);
+                v1 = key_valid(n);
+            }
+            float e0, e1;
+            exact_pair(b, v0 ? c0 : 0u, v1 ? c1 : 0u, e0, e1);
+            Best1 wp, wn;
+            if (!MATCHED) {
+                if (v0) {
+                    const float d1 = sqrtf(e0);
+                    wp.d = d1; wp.i = c0;
+                    if (v1) {
+                        const float d2 = sqrtf(e1);
+                        if (lexless(d2, c1, d1, c0)) { wp.d = d2; wp.i = c1; }
+                    }
+                    unsafe |= !(wp.d < INFINITY);
+                } else {
+                    unsafe = true;
+                }
+            } else {
+                if (v0) { wp.d = sqrtf(e0); wp.i = c0; unsafe |= !(wp.d < INFINITY); }
+                if (v1) { wn.d = sqrtf(e1); wn.i = c1; unsafe |= !(wn.d < INFINITY); }
+            }
+            if (__builtin_amdgcn_ballot_w64(unsafe) != 0ull) {
+                // exact scan in index order (helpers.rs:55-77 in f32), two prototypes per sweep over the rows; the
+                // whole wave walks it, lanes whose screening was usable keep their result
+                Best1 sp, sn;
+                for (uint32_t k = 0; k < a.K; k += 2) {
+                    const uint32_t kb = k + 1 < a.K ? k + 1 : k;
+                    float s0, s1;
+                    exact_pair(b, k, kb, s0, s1);
+                    const float d0 = sqrtf(s0), d1 = sqrtf(s1);
+                    if (!MATCHED || a.cls[k] == label) sp.offer(d0, k); else sn.offer(d0, k);
+                    if (kb != k) {
+                        if (!MATCHED || a.cls[kb] == label) sp.offer(d1, kb); else sn.offer(d1, kb);
+                    }
+                }
+                if (unsafe) { wp = sp; wn = sn; }
+            }
+            settle_ties<MATCHED>(a, label, wp, wn);
+            {
+                const int rec = (int)records(b, 4u);
+                const uint32_t so = (uint32_t)s_col * 4u;
+                auto put = [&](void *base, uint32_t bits) {
+                    __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+                };
+                if (h == 0) {
+                    if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                    if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+                } else {
+                    if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                    if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+                }
+            }
+            fetch_x(xa, bnext, 0);                     // the next batch's first chunk
+            fetch_label(q, nb0 + q);
+        }
+        block0 = nb0;
+    }
+}
+
+namespace {
+template <int NT>
+hipError_t launch_long(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_long<NT, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_long<NT, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn long_launcher(int tiles)
+{
+    switch (tiles) {
+    case 1: return &launch_long<1>;
+    case 2: return &launch_long<2>;
+    case 4: return &launch_long<4>;
+    default: return nullptr;
+    }
+}
+
+}  // namespace vq

@@ -22,6 +22,7 @@ LaunchFn resident_pipe_launcher(int R, bool diag);                              
 LaunchFn resident_staged_launcher(int R, size_t *staging_bytes);
 LaunchFn omega_pipe_launcher(int R);                                             // kernels_omega.hip: k_omega_pipe
 LaunchFn lowrank_launcher(int R1);                                               // kernels_omega.hip: k_lowrank_pipe
+LaunchFn long_launcher(int tiles);                                               // kernels_long.hip: k_long (rows above 256 values)
 
 // batch counters of one launch (BlockQueue, mfma_device.h): QUEUE_GROUPS counters, 4 KiB apart
 constexpr uint32_t QUEUE_GROUPS = 16;
