@@ -262,13 +262,14 @@ def test_host_path_multi_chunk(ctx):
 def test_host_path_multi_chunk_shared_scratch_and_queues(ctx):
     """Chunks alternate between two streams: the scalar Omega path shares one projection scratch buffer
     between them, the MFMA kernels one set of batch counters.  Every chunk must come out whole."""
-    m = _model(("t", "LiRaMLVQ", 1, 300, 6, 3, "global"))             # D = 300 > 256: scalar kernels, 111K-row chunks
+    m = _model(("t", "LiRaMLVQ", 1, 300, 6, 3, "global"))             # 111K-row chunks
     N = (128 << 20) // 1200 * 2 + 4321
     X = synth.samples_host(m, 0, N)
-    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_kernel_policy(KERNEL_SCALAR)                               # the scalar Omega path: project into scratch, search
     synth.load_model(ctx, m, with_labels=False)
     idx, dist = ctx.assign(X)
     assert ctx.last_kernel == "scalar"
+    ctx.set_kernel_policy(KERNEL_AUTO)
     for lo in (0, N // 3, N // 2 - 300, N - 2000):
         o = oracle.assign(X[lo:lo + 2000], m.W, omega=m.omega, threads=8)
         rep = parity.compare(idx[lo:lo + 2000], dist[lo:lo + 2000], *o, atol=2e-6)
@@ -760,4 +761,43 @@ def test_long_rows(ctx, case):
         f2 = np.isfinite(d) | ~np.isfinite(om[1])        # rows with no eligible prototype: +INF on both sides
         f2 &= fin | ~np.isfinite(om[1])
         rep = parity.compare(j[f2], d[f2], om[0][f2], om[1][f2], om[2][f2])
+        assert rep.ok, f"{case} matching={matching}: {rep}"
+
+
+@pytest.mark.parametrize("case", [(600, 784, 40, 16), (300, 300, 100, 40), (200, 512, 10, 128), (40, 1000, 257, 3)],
+                         ids=lambda c: "n%d_d%d_k%d_m%d" % c)
+def test_long_rows_omega(ctx, case):
+    """Global Omega over rows above 256 values (k_omega_long: projection in chunks of 64, search in the projected
+    space as in k_omega_pipe): plain and matched against the oracle, NaN / INF rows, nothing written past N."""
+    import torch
+    N, D, K, M = case
+    rng = np.random.default_rng(N + D + K + M)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 2, D)).astype(np.float32)
+    X[5 % N, D - 1] = np.nan
+    X[17 % N, 300 % D] = np.inf
+    o = oracle.assign(X[:N], W, omega=Om, threads=8)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    ctx.set_omega(Om)
+    Xd = torch.from_numpy(X).cuda()
+    idx = torch.full((N + 2,), -7, dtype=torch.int32, device="cuda")
+    dist = torch.full((N + 2,), -7.0, dtype=torch.float32, device="cuda")
+    ctx.assign_into(Xd[:N], idx[:N], dist[:N])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "mfma_omega_long"
+    assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()
+    gi, gd = idx[:N].cpu().numpy(), dist[:N].cpu().numpy()
+    rep = parity.compare(gi, gd, *o, atol=2e-6)
+    print(case, rep)
+    assert rep.ok, str(rep)
+    assert gi[5 % N] == 0 and np.isinf(gd[5 % N]) and gi[17 % N] == 0 and np.isinf(gd[17 % N])
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    ctx.set_labels(cls)
+    jp, dp, jn, dn = ctx.assign_matched(X[:N], y)
+    assert ctx.last_kernel == "mfma_omega_long"
+    for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+        rep = parity.compare(j, d, *oracle.assign(X[:N], W, omega=Om, proto_cls=cls, labels=y, matching=matching, threads=8), atol=2e-6)
         assert rep.ok, f"{case} matching={matching}: {rep}"

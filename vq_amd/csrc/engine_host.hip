@@ -145,6 +145,39 @@ bool bind_long(EngineModel &m, std::vector<float> &img1, std::vector<float> &img
     return true;
 }
 
+// Global Omega (at most R2 <= 128 rows) over rows above 256 values: k_omega_long.  img1 = A-fragment pieces of
+// Omega per (chunk, tile of 32 Omega rows, step) as in bind_long, img2 = tile image of the projected prototypes.
+template <int R2>
+bool bind_omega_long(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
+                     const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
+{
+    if (m.D <= 256 || (uint32_t)pad_pow2(m.M, 32) != (uint32_t)R2) return false;
+    if ((size_t)res_tiles(m.K) * Geom<R2>::TILE_BYTES > (size_t)RES_BYTES) return false;
+    const LaunchFn fn = omega_long_launcher(R2);
+    if (!fn) return false;
+    constexpr uint32_t tiles = R2 / 32;
+    const uint32_t NC = (m.D + 63) / 64;                              // this kernel's chunks hold 64 values: 8 steps
+    img1.assign((size_t)NC * tiles * 8 * 64 * 4, 0.0f);
+    for (uint32_t c = 0; c < NC; ++c)
+        for (uint32_t t = 0; t < tiles; ++t)
+            for (uint32_t j = 0; j < 8; ++j)
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t r = 32 * t + (lane & 31), d0 = 64 * c + 4 * (2 * j + (lane >> 5));
+                    float *dst = &img1[((((size_t)c * tiles + t) * 8 + j) * 64 + lane) * 4];
+                    for (uint32_t e = 0; e < 4; ++e)
+                        if (r < m.M && d0 + e < m.D) dst[e] = Om[(size_t)r * m.D + d0 + e];
+                }
+    uint32_t ngroups2 = 0;
+    img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE, ngroups2);
+    m.ngroups2 = ngroups2;
+    m.R2 = R2;
+    m.ldp = R2;
+    m.launch = fn;
+    m.samples_per_batch = 32;
+    m.name = "mfma_omega_long";
+    return true;
+}
+
 template <int R1, int R2>
 bool bind_omega(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
                 const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
@@ -253,8 +286,9 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                           hipError_t &herr)
 {
     herr = hipSuccess;
-    if (D > 256 && !(omega_kind == OMEGA_NONE && K <= 128 && D <= 65536 && !getenv("VQHIP_NO_LONG"))) {
-        why = "sample length above 256 (served for Euclidean models with at most 128 prototypes)";
+    if (D > 256 && !(((omega_kind == OMEGA_NONE && K <= 128) || (omega_kind == OMEGA_GLOBAL && M <= 128)) && D <= 65536 &&
+                     !getenv("VQHIP_NO_LONG"))) {
+        why = "sample length above 256 (served for Euclidean models with at most 128 prototypes and for a global Omega of at most 128 rows)";
         return nullptr;
     }
     if (omega_kind != OMEGA_NONE && M > 256) {
@@ -311,7 +345,9 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
             m.name = "mfma_omega";
             m.R2 = (uint32_t)pad_pow2(M, 16);
             m.ldp = m.R2;
-            ok = bind_lowrank<256>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<128>(m, img1, img2, Om, P, norms, cls) ||
+            ok = bind_omega_long<32>(m, img1, img2, Om, P, norms, cls) || bind_omega_long<64>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_omega_long<128>(m, img1, img2, Om, P, norms, cls) ||
+                 bind_lowrank<256>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<128>(m, img1, img2, Om, P, norms, cls) ||
                  bind_lowrank<64>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<32>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega_pipe<128>(m, img1, img2, Om, P, norms, cls) || bind_omega_pipe<64>(m, img1, img2, Om, P, norms, cls) ||
                  bind_omega_pipe<32>(m, img1, img2, Om, P, norms, cls) ||

@@ -257,6 +257,167 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------ Omega models with long rows
+// GMLVQ / LiRaMLVQ with rows above 256 values and an Omega of at most 128 rows (src/helpers.rs:35-45 through
+// 55-77, 91-132).  The projection y = Omega x runs over chunks of 64 values like pass 1 of k_long -- Omega's A
+// fragments from L2 through the ring, all R2 / 32 tiles of Omega rows accumulating at once -- and leaves y in the
+// accumulators, which are the search stage's B fragment (engine.h).  From there on it is k_omega_pipe: projected
+// prototypes resident in LDS, pipelined packed-key search, exact re-measurement ||y - p_k||^2 (squared) from the LDS
+// image.  The search space is y, which stays in registers, so the rows are fetched once.
+template <int R2, bool MATCHED, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs a)
+{
+    using Gs = Geom<R2>;
+    constexpr int NT = R2 / 32, NJ = 8, DEPTH = 8;        // chunks of 64 values here: two chunk sets, Omega's tiles and y share the registers
+    constexpr uint32_t CHUNK = NJ * 8;
+    __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ntiles = a.res_tiles;
+    const uint32_t NC = (a.D + CHUNK - 1) / CHUNK, npieces = NC * NT * NJ;
+    {   // projected prototypes -> LDS
+        const uint32_t bytes = ntiles * Gs::TILE_BYTES;
+        const char *src = (const char *)a.img2;
+        for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
+            const uint32_t off = p * 1024u + lane * 16u;
+            if (off < bytes)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
+                                                 (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float *img = (const float *)smem;
+    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, (int)(npieces * 1024u), 0x00020000);
+    const uint32_t om_off = (uint32_t)lane * 16u;
+    auto piece = [&](uint32_t p) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, (int)(p * 1024u), 0));
+    };
+
+    constexpr uint32_t BLOCK = 2;
+    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    queue.request();
+
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    f32x4 xa[NJ], xb[NJ];
+    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
+    };
+    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
+        if ((c + 1u) * CHUNK > a.D) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
+        }
+    };
+    uint32_t ln[BLOCK];
+#pragma unroll
+    for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
+    auto fetch_label = [&](uint32_t q, uint64_t bb) {
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    fetch_x(xa, block0, 0);
+    fetch_label(0, block0);
+    fetch_label(1, block0 + 1);
+
+    while (block0 < a.nbatches) {
+        const uint64_t nb0 = queue.take();
+        queue.request();
+#pragma unroll
+        for (uint32_t q = 0; q < BLOCK; ++q) {
+            const uint64_t b = block0 + q;
+            const uint64_t bnext = q + 1 < BLOCK ? b + 1 : nb0;
+            const uint32_t label = ln[q];
+
+            // ---- projection over the chunks: acc[t] = rows 32 t .. 32 t + 31 of Omega x
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            f32x4 ring[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = piece((uint32_t)i);
+            uint32_t pnext = DEPTH;
+            auto mma = [&](const f32x4 (&xs)[NJ]) {
+                static_for<0, NT>([&](auto tt) {
+                    static_for<0, NJ>([&](auto jj) {
+                        constexpr int j = decltype(jj)::value;
+                        const f32x4 av = ring[j % DEPTH];
+                        ring[j % DEPTH] = piece(pnext++);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[decltype(tt)::value] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xs[j][e], acc[decltype(tt)::value], 0, 0, 0);
+                    });
+                });
+            };
+            for (uint32_t c = 0; c < NC; c += 2) {
+                if (c + 1 < NC) fetch_x(xb, b, c + 1);
+                cut(xa, c);
+                mma(xa);
+                if (c + 1 < NC) {
+                    if (c + 2 < NC) fetch_x(xa, b, c + 2);
+                    cut(xb, c + 1);
+                    mma(xb);
+                }
+            }
+            f32x4 yf[R2 / 8];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) yf[4 * t + g] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            asm volatile("" ::: "memory");
+            fetch_x(xa, bnext, 0);                     // x is dead: the next batch's first chunk lands during the search
+            fetch_label(q, nb0 + q);
+
+            float ss = 0.0f;
+#pragma unroll
+            for (int j = 0; j < R2 / 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
+            ss += xor32(ss);
+            const bool unsafe = !(ss < a.ss_limit);
+            const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+
+            Keys2 ku;
+            KeysM km;
+            search_tiles<R2, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
+            Best1 wp, wn;
+            finish_keys<R2, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
+            settle_ties<MATCHED>(a, label, wp, wn);
+            {
+                const int rec = (int)records(b, 4u);
+                const uint32_t so = (uint32_t)s_col * 4u;
+                auto put = [&](void *base, uint32_t bits) {
+                    __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+                };
+                if (h == 0) {
+                    if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                    if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+                } else {
+                    if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                    if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+                }
+            }
+        }
+        block0 = nb0;
+    }
+}
+
 namespace {
 template <int NT>
 hipError_t launch_long(const EngineArgs &a, bool matched, hipStream_t st)
@@ -272,6 +433,32 @@ hipError_t launch_long(const EngineArgs &a, bool matched, hipStream_t st)
     return hipGetLastError();
 }
 }  // namespace
+
+namespace {
+template <int R2>
+hipError_t launch_omega_long(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_omega_long<R2, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_omega_long<R2, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn omega_long_launcher(int R2)
+{
+    switch (R2) {
+    case 32: return &launch_omega_long<32>;
+    case 64: return &launch_omega_long<64>;
+    case 128: return &launch_omega_long<128>;
+    default: return nullptr;
+    }
+}
 
 LaunchFn long_launcher(int tiles)
 {
