@@ -127,9 +127,9 @@ int vqhip_assign_matched_device(vqhip_ctx *ctx, const float *dX, const uint32_t 
  *                                               LiRaMLVQ::project  src/liramlvq/liramlvq.rs:401-419
  *                         with local Omegas: Y_i = Lambda_j x_i, j = nearest local prototype of x_i
  *                                               LGMLVQ::project    src/lgmlvq/lgmlvq.rs:372-393
- * A global Omega with D in {32, 64, 128, 256} and an output width that is a multiple of 4 runs on the
- * matrix cores (k_project: Omega / Lambda resident in LDS; Lambda is built once in f64 as the reference
- * builds it once, gmlvq.rs:357-358); LGMLVQ and the remaining shapes run on the scalar kernels. */
+ * A global Omega with D <= 256 runs on the matrix cores (k_project: Omega / Lambda resident in LDS; Lambda is
+ * built once in f64 as the reference builds it once, gmlvq.rs:357-358); LGMLVQ and D > 256 run on the
+ * scalar kernels. */
 typedef enum { VQHIP_PROJECT_OMEGA = 0, VQHIP_PROJECT_LAMBDA = 1 } vqhip_projection;
 int vqhip_project(vqhip_ctx *ctx, const float *X, uint64_t N, int which /* vqhip_projection */, float *Y);
 int vqhip_project_device(vqhip_ctx *ctx, const float *dX, uint64_t N, int which, float *dY, void *stream);

@@ -444,21 +444,21 @@ def test_project_global(ctx, shape):
     Z = ctx.project(X, PROJECT_OMEGA)                                     # liramlvq.rs:429-446
     assert Z.shape == (m.cfg.N, m.cfg.M)
     assert _rel_err(Z, oracle.project_omega(m.omega, X)) < 1e-5
-    # the matrix-core kernel serves D in {32, 64, 128, 256} (and output widths that are multiples of 4)
-    on_mfma = m.cfg.D in (32, 64, 128, 256)
-    assert lam_kernel == ("mfma_project" if on_mfma else "scalar_project")
-    assert ctx.last_kernel == ("mfma_project" if on_mfma and m.cfg.M % 4 == 0 else "scalar_project")
+    # the matrix-core kernel serves every D <= 256 and every output width
+    assert lam_kernel == "mfma_project" and ctx.last_kernel == "mfma_project"
     ctx.set_kernel_policy(KERNEL_SCALAR)                                  # the scalar kernels stay the cross-check
     assert _rel_err(ctx.project(X, PROJECT_LAMBDA), oracle.project_lambda(m.omega, X)) < 1e-5
     assert ctx.last_kernel == "scalar_project"
     ctx.set_kernel_policy(KERNEL_AUTO)
 
 
-@pytest.mark.parametrize("case", [(1, 128, 128), (33, 64, 20), (4097, 256, 16), (1000, 256, 200), (95, 32, 7), (64, 128, 36)],
+@pytest.mark.parametrize("case", [(1, 128, 128), (33, 64, 20), (4097, 256, 16), (1000, 256, 200), (95, 32, 7), (64, 128, 36),
+                                  (777, 126, 5), (300, 10, 10), (2049, 200, 33), (65, 3, 2)],
                          ids=lambda c: "n%d_d%d_m%d" % c)
 def test_project_mfma_kernel(ctx, case):
     """k_project: row counts around the 32-row batch, output widths that end inside a tile / inside a group of
-    8 columns, Lambda of 256 x 256 (two column blocks), nothing written past N (gmlvq.rs:354-372, liramlvq.rs:401-446)."""
+    8 columns / that are not multiples of 4 (4-byte stores), row lengths off the power-of-two grid (cut at D),
+    Lambda of 256 x 256 (two column blocks), nothing written past N (gmlvq.rs:354-372, liramlvq.rs:401-446)."""
     import torch
     from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
     N, D, M = case
@@ -473,7 +473,7 @@ def test_project_mfma_kernel(ctx, case):
         Y = torch.full((N + 2, width), -7.0, dtype=torch.float32, device="cuda")
         ctx.project_into(Xd[:N], Y[:N], which)
         torch.cuda.synchronize()
-        assert ctx.last_kernel == ("mfma_project" if width % 4 == 0 else "scalar_project")
+        assert ctx.last_kernel == "mfma_project"
         assert (Y[N:].cpu().numpy() == -7.0).all()
         assert _rel_err(Y[:N].cpu().numpy(), want) < 1e-5
 

@@ -344,7 +344,7 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
     if (c->omega_kind == OMEGA_GLOBAL && c->policy != VQHIP_KERNEL_SCALAR) {
         const ProjectModel *pm = which == VQHIP_PROJECT_OMEGA ? c->proj_omega : c->proj_lambda;
         const uint32_t ldy = project_width(c, which);
-        if (pm && ldy % 4 == 0 && ((uintptr_t)dY & 15) == 0 && ((uintptr_t)dX & 15) == 0) {
+        if (pm && ((uintptr_t)dY & 3) == 0 && ((uintptr_t)dX & 3) == 0) {
             c->last_kernel = "mfma_project";
             HIPCHK(c, project_run(pm, dX, N, dY, ldy, s));
             return VQHIP_OK;

@@ -17,8 +17,9 @@ namespace vq {
 // stored as 16 bytes (the lane pair writes 32 adjacent bytes, the 4 groups of a tile a whole 128-byte line
 // per sample).  Columns at or past out_dim and rows past N are not written (predicate / buffer range check).
 struct ProjectArgs {
-    const float *X;
+    const float *X;           // N x D, rows 4-byte aligned
     uint64_t N;
+    uint32_t D;               // <= R; values at or past D are cut inside the kernel
     const float *img;         // ntiles tiles of Geom<R>
     uint32_t ntiles;
     float *Y;                 // N x ldy
@@ -27,7 +28,8 @@ struct ProjectArgs {
     uint32_t *queue;
 };
 
-template <int R, int NW = 8>
+// CUT: rows shorter than R (any length, 4-byte aligned): one register set, cut at D in place once it has landed.
+template <int R, bool CUT, int NW = 8>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a)
 {
     using Gm = Geom<R>;
@@ -35,7 +37,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
     // out right behind its last MFMA and have the other set's whole batch to land, with no copies between
     // sets.  R = 256: one set is all the register file holds at two waves per SIMD; the partner wave of
     // the SIMD covers the wait.
-    constexpr int SETS = R <= 128 ? 2 : 1;
+    constexpr int SETS = R <= 128 && !CUT ? 2 : 1;
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
     uint64_t blk = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * SETS;
     queue.request();
 
-    const uint32_t row_bytes = R * 4u;
+    const uint32_t row_bytes = a.D * 4u;
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
     auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
         const uint64_t first = bb * 32;
@@ -68,7 +70,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
     f32x4 x[SETS][R / 8];
     auto fetch = [&](f32x4 (&xs)[R / 8], uint64_t bb) {
         const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R), 0, (int)records(bb, row_bytes), 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
         // issue order = use order: vmcnt counts in order, and a set's first chunk must not wait for the
         // loads issued behind it (its own later chunks, the other set's refill)
 #pragma unroll
@@ -83,7 +85,12 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
     const uint32_t yoff = (uint32_t)s_col * ybytes;
 
     // all tiles of one batch: Y[b*32 + s][col0 + 32 t + 8 g + 4 h .. + 3] = accumulator group g of tile t
-    auto project_batch = [&](const f32x4 (&xs)[R / 8], uint64_t bb, bool claim) {
+    const bool vec_store = (a.ldy & 3u) == 0u && ((uintptr_t)a.Y & 15u) == 0u;    // else 4-byte stores, column by column
+    auto project_batch = [&](f32x4 (&xs)[R / 8], uint64_t bb, bool claim) {
+        if constexpr (CUT) {
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) xs[j] = mask_chunk(xs[j], (uint32_t)(2 * j + h), a.D);
+        }
         const __amdgpu_buffer_rsrc_t ry =
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Y + bb * 32 * a.ldy), 0, (int)records(bb, ybytes), 0x00020000);
         for (uint32_t t = 0; t < a.ntiles; ++t) {
@@ -107,9 +114,16 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const uint32_t col = a.col0 + 32u * t + 8u * g + 4u * h;
-                if (col < a.out_dim) {
+                if (vec_store && col + 4u <= a.out_dim) {
                     const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, yoff + col * 4u, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = acc[4 * g + e];      // (a bit_cast of the vector element itself stores element 0)
+                        if (col + e < a.out_dim)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ry, yoff + (col + e) * 4u, 0, 0);
+                    }
                 }
             }
         }
@@ -144,14 +158,17 @@ hipError_t launch_project_t(const ProjectArgs &a, hipStream_t st)
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_project<R>), dim3(grid), dim3(512), 0, st, a);
+    if (a.D < (uint32_t)R)
+        hipLaunchKernelGGL((k_project<R, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_project<R, false>), dim3(grid), dim3(512), 0, st, a);
     return hipGetLastError();
 }
 
 template <int R>
 bool bind_project(ProjectModel &m, std::vector<float> &img, const std::vector<float> &A)
 {
-    if (m.D != (uint32_t)R) return false;
+    if (m.D > (uint32_t)R || (R > 32 && m.D <= (uint32_t)R / 2)) return false;       // narrowest instantiation that holds a row
     uint32_t ngroups = 0;
     img = build_images<R>(A.data(), m.rows, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, ngroups);
     m.R = R;
@@ -196,7 +213,7 @@ hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float
     if (N == 0) return hipSuccess;
     for (uint32_t t0 = 0; t0 < m->ntiles; t0 += m->tiles_per_launch) {
         ProjectArgs a;
-        a.X = dX; a.N = N;
+        a.X = dX; a.N = N; a.D = m->D;
         a.img = m->img + (size_t)t0 * m->tile_floats;
         a.ntiles = std::min(m->tiles_per_launch, m->ntiles - t0);
         a.Y = dY; a.ldy = ldy; a.col0 = t0 * 32u; a.out_dim = m->rows;
