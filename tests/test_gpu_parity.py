@@ -721,7 +721,8 @@ def test_row_lengths_that_are_not_multiples_of_four(ctx, D):
         assert rep.ok, str(rep)
 
 
-@pytest.mark.parametrize("case", [(2000, 300, 50), (1500, 784, 10), (700, 257, 128), (333, 1000, 33), (65, 2049, 3), (4097, 512, 64)],
+@pytest.mark.parametrize("case", [(2000, 300, 50), (1500, 784, 10), (700, 257, 128), (333, 1000, 33), (65, 2049, 3), (4097, 512, 64),
+                                  (500, 300, 200), (300, 513, 256)],
                          ids=lambda c: "n%d_d%d_k%d" % c)
 def test_long_rows(ctx, case):
     """Rows above 256 values (k_long: the reduction in chunks of 128, candidates re-measured in a second sweep):

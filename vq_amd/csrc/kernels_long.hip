@@ -1,5 +1,5 @@
 // Euclidean models with rows longer than 256 values (VQ / LVQ / GLVQ: src/helpers.rs:11-24, 55-77, 91-132) on the
-// matrix cores, for up to 128 prototypes.  The reduction runs over chunks of 128 values:
+// matrix cores, for up to 256 prototypes.  The reduction runs over chunks of 128 (more than 64 prototypes: 64) values:
 //   pass 1  every chunk of the wave's 32 rows is fetched once and multiplied into ALL the tiles' accumulators
 //           (NT x 16 registers stay live across the chunks); the prototypes' A fragments stream from L2 through a
 //           register ring, one 1 KiB piece per (chunk, tile, step), so there is no LDS stage and no barrier;
@@ -16,11 +16,14 @@ namespace vq {
 template <int NT, bool MATCHED, int NW = 8>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
 {
-    constexpr int NJ = 16, DEPTH = 8;                  // steps of 4 MFMAs per chunk and tile; pieces in flight
+    // chunks of 128 values (16 steps of 4 MFMAs per tile) while the accumulators of up to 2 tiles leave room for
+    // two chunk sets of that size, chunks of 64 values for 4 and 8 tiles; DEPTH pieces in flight
+    constexpr int NJ = NT <= 2 ? 16 : 8, DEPTH = 8;
+    constexpr uint32_t CHUNK = NJ * 8;
     static_assert(NJ % DEPTH == 0, "ring slots are compile-time");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
-    const uint32_t NC = a.nchunks, npieces = NC * NT * NJ;
+    const uint32_t NC = (a.D + CHUNK - 1) / CHUNK, npieces = NC * NT * NJ;
 
     // A fragments: piece p = (chunk * NT + tile) * NJ + step, this lane's 16 bytes at p * 1024 + lane * 16
     const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, (int)(npieces * 1024u), 0x00020000);
@@ -50,13 +53,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * 512u), 0));
+            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
     };
     // values at or past D (the last chunk's tail: the next row, or range-check zeros) are cleared
     auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
-        if ((c + 1u) * 128u > a.D) {
+        if ((c + 1u) * CHUNK > a.D) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * 32u + (uint32_t)(2 * j + h), a.D);
+            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
         }
     };
     // fn(chunk registers, chunk number) over all chunks of batch bb; xa must hold (or be receiving) chunk 0
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
         for_chunks(bb, [&](const f32x4 (&xs)[NJ], uint32_t c) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const f32x4 v0 = *(const f32x4 *)(w0 + c * 128u + 8 * j), v1 = *(const f32x4 *)(w1 + c * 128u + 8 * j);
+                const f32x4 v0 = *(const f32x4 *)(w0 + c * CHUNK + 8 * j), v1 = *(const f32x4 *)(w1 + c * CHUNK + 8 * j);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d0 = xs[j][e] - v0[e], d1 = xs[j][e] - v1[e];
@@ -466,6 +469,7 @@ LaunchFn long_launcher(int tiles)
     case 1: return &launch_long<1>;
     case 2: return &launch_long<2>;
     case 4: return &launch_long<4>;
+    case 8: return &launch_long<8>;
     default: return nullptr;
     }
 }

@@ -31,7 +31,6 @@ struct EngineArgs {
     uint32_t K;               // actual number of prototypes
     uint32_t tiles_per_proto; // LOCAL: 32-row tiles per Omega_j
     uint32_t res_tiles;       // resident kernels: tiles of 32 prototypes actually searched, ceil(K / 32)
-    uint32_t nchunks;         // k_long: chunks of 128 values per row, ceil(D / 128)
     uint64_t nbatches;
     Outputs out;
     float wmax2;              // largest ||w_k||^2 (screening error bound)
