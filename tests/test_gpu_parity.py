@@ -706,10 +706,24 @@ def test_row_lengths_that_are_not_multiples_of_four(ctx, D):
     ctx.set_kernel_policy(KERNEL_AUTO)
     ctx.set_prototypes(W)
     idx, dist = ctx.assign(X)
-    assert ctx.last_kernel.startswith("mfma_euclid"), ctx.last_kernel
+    # up to 128 values the prototypes are LDS-resident (pipelined kernel, CUT); 129..256 run on the streamed engine
+    want = "mfma_euclid_lds" if D <= 32 else ("mfma_euclid_lds_pipe_cut" if D <= 128 else "mfma_euclid")
+    assert ctx.last_kernel == want, ctx.last_kernel
     rep = parity.compare(idx, dist, *o)
     assert rep.ok, str(rep)
     assert np.isfinite(dist[clean]).all() and (idx[~clean] == 0).all() and np.isinf(dist[~clean]).all()
+    # the same model on the unpipelined padded-row kernel (k_resident): same winners wherever the gap is clear
+    import os
+    os.environ["VQHIP_NO_CUT"] = "1"
+    try:
+        ctx.set_prototypes(W)
+        idx2, dist2 = ctx.assign(X)
+        assert ctx.last_kernel == ("mfma_euclid_lds" if D <= 128 else "mfma_euclid")
+    finally:
+        del os.environ["VQHIP_NO_CUT"]
+    rep2 = parity.compare(idx2, dist2, *o)
+    assert rep2.ok and (idx2 != idx).sum() <= rep.near_ties + rep2.near_ties, f"{rep} / {rep2}"
+    ctx.set_prototypes(W)
     if D >= 3:
         M = 3
         Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)

@@ -104,6 +104,13 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
                     m.launch = staged;
                     m.name = "mfma_euclid_lds_staged";
                 }
+            } else if (R1 >= 64 && m.D < (uint32_t)R1 && !getenv("VQHIP_NO_PIPE") && !getenv("VQHIP_NO_CUT")) {
+                // rows shorter than R1: the pipelined kernel cuts its fetches at D.  Measured against k_resident (two
+                // 32-sample tiles per wave, no prefetch): +15 % at D=126, K=256, +35 % at D=100, K=37, equal at D=30,
+                // slower at D=10 -- rows of up to 32 values stay on k_resident.
+                m.samples_per_batch = 32;
+                m.launch = resident_cut_launcher(R1);
+                m.name = "mfma_euclid_lds_pipe_cut";
             }
         }
     }

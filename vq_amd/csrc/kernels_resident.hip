@@ -157,7 +157,10 @@ struct Staging {
     __host__ __device__ static constexpr int row_off(int r) { return (r / ROWS_PER_PIECE) * PIECE_STRIDE + (r % ROWS_PER_PIECE) * R * 4; }
 };
 
-template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false>
+//
+// CUT: rows shorter than R (any length, 4-byte aligned; the image is zero padded): the 16-byte fetches are cut at
+// D in place once a set has landed (mask_chunk).
+template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false, bool CUT = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
 {
     using Gm = Geom<R>;
@@ -256,6 +259,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             f32x4(&xf)[R / 8] = x[set];
             using f32x2 = __attribute__((ext_vector_type(2))) float;
             f32x2 ss2 = {0.0f, 0.0f};
+            if constexpr (CUT) {
+#pragma unroll
+                for (int j = 0; j < R / 8; ++j) xf[j] = mask_chunk(xf[j], (uint32_t)(2 * j + h), a.D);
+            }
             if constexpr (STAGED) {
                 // everything older than the stores of the previous batch has landed, the pieces among it; the
                 // fragments are out of the buffer (lgkmcnt) before the next batch's pieces are sent into it
@@ -354,6 +361,20 @@ hipError_t launch_resident_staged(const EngineArgs &a, bool matched, hipStream_t
     return hipGetLastError();
 }
 
+template <int R>
+hipError_t launch_resident_cut(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, false, true>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
 template <int R, bool DIAG>
 hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t st)
 {
@@ -392,6 +413,17 @@ LaunchFn resident_staged_launcher(int R, size_t *staging_bytes)
     case 32: *staging_bytes = 8 * Staging<32>::BYTES; return &launch_resident_staged<32>;
     case 64: *staging_bytes = 8 * Staging<64>::BYTES; return &launch_resident_staged<64>;
     case 128: *staging_bytes = 8 * Staging<128>::BYTES; return &launch_resident_staged<128>;
+    default: return nullptr;
+    }
+}
+
+LaunchFn resident_cut_launcher(int R)
+{
+    switch (R) {
+    case 16: return &launch_resident_cut<16>;
+    case 32: return &launch_resident_cut<32>;
+    case 64: return &launch_resident_cut<64>;
+    case 128: return &launch_resident_cut<128>;
     default: return nullptr;
     }
 }
