@@ -706,8 +706,8 @@ def test_row_lengths_that_are_not_multiples_of_four(ctx, D):
     ctx.set_kernel_policy(KERNEL_AUTO)
     ctx.set_prototypes(W)
     idx, dist = ctx.assign(X)
-    # up to 128 values the prototypes are LDS-resident (pipelined kernel, CUT); 129..256 run on the streamed engine
-    want = "mfma_euclid_lds" if D <= 32 else ("mfma_euclid_lds_pipe_cut" if D <= 128 else "mfma_euclid")
+    # up to 32 values k_resident, above that the pipelined kernel's CUT variant (one register set above 128 values)
+    want = "mfma_euclid_lds" if D <= 32 else "mfma_euclid_lds_pipe_cut"
     assert ctx.last_kernel == want, ctx.last_kernel
     rep = parity.compare(idx, dist, *o)
     assert rep.ok, str(rep)

@@ -88,30 +88,31 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     img = build_images<R1>(W.data(), m.K, m.D, m.D, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
                            m.ngroups1);
     m.launch = streamed_launcher(MODE_EUCLID, R1, R1, &m.samples_per_batch);
-    if constexpr (R1 < 256) {
-        if ((size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
+    if ((size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES <= (size_t)RES_BYTES && !getenv("VQHIP_NO_RESIDENT")) {
+        const bool pipe_ok = !getenv("VQHIP_NO_PIPE");
+        if (R1 < 256) {
             m.launch = resident_launcher(R1, &m.samples_per_batch);
             m.name = "mfma_euclid_lds";
-            if (m.D == (uint32_t)R1 && !getenv("VQHIP_NO_PIPE")) {       // unpadded rows: the pipelined kernel
-                m.samples_per_batch = 32;
-                m.launch = resident_pipe_launcher(R1, variant_env() == 31);
-                m.name = "mfma_euclid_lds_pipe";
-                // few prototypes: the search is short, the memory pipe binds, rows are staged through LDS
-                size_t staging = 0;
-                const LaunchFn staged = resident_staged_launcher(R1, &staging);
-                if (staged && res_tiles(m.K) <= 2 && (size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES + staging <= (size_t)RES_BYTES &&
-                    variant_env() != 31 && !getenv("VQHIP_NO_STAGED")) {
-                    m.launch = staged;
-                    m.name = "mfma_euclid_lds_staged";
-                }
-            } else if (R1 >= 64 && m.D < (uint32_t)R1 && !getenv("VQHIP_NO_PIPE") && !getenv("VQHIP_NO_CUT")) {
-                // rows shorter than R1: the pipelined kernel cuts its fetches at D.  Measured against k_resident (two
-                // 32-sample tiles per wave, no prefetch): +15 % at D=126, K=256, +35 % at D=100, K=37, equal at D=30,
-                // slower at D=10 -- rows of up to 32 values stay on k_resident.
-                m.samples_per_batch = 32;
-                m.launch = resident_cut_launcher(R1);
-                m.name = "mfma_euclid_lds_pipe_cut";
+        }
+        if (m.D == (uint32_t)R1 && pipe_ok && resident_pipe_launcher(R1, variant_env() == 31)) {   // unpadded rows: the pipelined kernel
+            m.samples_per_batch = 32;
+            m.launch = resident_pipe_launcher(R1, variant_env() == 31);
+            m.name = "mfma_euclid_lds_pipe";
+            // few prototypes: the search is short, the memory pipe binds, rows are staged through LDS
+            size_t staging = 0;
+            const LaunchFn staged = resident_staged_launcher(R1, &staging);
+            if (staged && res_tiles(m.K) <= 2 && (size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES + staging <= (size_t)RES_BYTES &&
+                variant_env() != 31 && !getenv("VQHIP_NO_STAGED")) {
+                m.launch = staged;
+                m.name = "mfma_euclid_lds_staged";
             }
+        } else if (R1 >= 64 && m.D < (uint32_t)R1 && pipe_ok && !getenv("VQHIP_NO_CUT")) {
+            // rows shorter than R1: the pipelined kernel cuts its fetches at D.  Measured against k_resident (two
+            // 32-sample tiles per wave, no prefetch): +15 % at D=126, K=256, +35 % at D=100, K=37, equal at D=30,
+            // slower at D=10 -- rows of up to 32 values stay on k_resident.
+            m.samples_per_batch = 32;
+            m.launch = resident_cut_launcher(R1);
+            m.name = "mfma_euclid_lds_pipe_cut";
         }
     }
     return true;

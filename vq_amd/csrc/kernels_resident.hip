@@ -209,7 +209,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     // right after its batch's epilogue and has the other batch's whole search to land -- no copies between sets.
     const uint32_t row_bytes = a.D * 4u;
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
-    constexpr int SETS = STAGED ? 1 : (int)BLOCK;      // STAGED: the rows wait in LDS, one register set serves
+    // STAGED: the rows wait in LDS, one register set serves.  R = 256: one set is all the register file holds at two
+    // waves per SIMD; it is refilled behind the epilogue for the very next batch and the partner wave covers the wait.
+    constexpr bool SINGLE = !STAGED && R > 128;
+    constexpr int SETS = STAGED || SINGLE ? 1 : (int)BLOCK;
     f32x4 x[SETS][R / 8];
     uint32_t ln[BLOCK];
 #pragma unroll
@@ -223,8 +226,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     // STAGED: this wave's 32-row staging buffer behind the image
     char *stage = smem + ntiles * Gm::TILE_BYTES + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * St::BYTES;
     // rows (and labels) of batch bb -> register set / label slot q, or -> the staging buffer
-    auto fetch = [&](auto qq, uint64_t bb) {
+    auto fetch = [&](auto qq, uint64_t bb) {           // qq: label slot = position of bb in its block
         constexpr int q = decltype(qq)::value;
+        constexpr int fset = SETS == 1 ? 0 : q;
         const __amdgpu_buffer_rsrc_t rx =
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
         if constexpr (STAGED) {
@@ -236,7 +240,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         } else {
 #pragma unroll
             for (int j = 0; j < R / 8; ++j)
-                x[q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+                x[fset][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
         }
         if (MATCHED) {
             const __amdgpu_buffer_rsrc_t ry =
@@ -244,7 +248,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
         }
     };
-    if constexpr (STAGED) {
+    if constexpr (SETS == 1) {
         fetch(std::integral_constant<int, 0>{}, block0);
     } else {
         static_for<0, (int)BLOCK>([&](auto qq) { fetch(qq, block0 + decltype(qq)::value); });
@@ -254,7 +258,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         const uint64_t nb0 = queue.take();             // first batch of the next block (the wait for its atomic is here)
         static_for<0, (int)BLOCK>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
-            constexpr int set = STAGED ? 0 : q;
+            constexpr int set = SETS == 1 ? 0 : q;
             const uint64_t b = block0 + q;
             f32x4(&xf)[R / 8] = x[set];
             using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -315,7 +319,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 }
             }
             // this set's rows are dead: refill it for the same position of the next block
-            if constexpr (!STAGED) {
+            if constexpr (SINGLE) {
+                asm volatile("" ::: "memory");
+                fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
+            } else if constexpr (!STAGED) {
                 asm volatile("" ::: "memory");
                 fetch(qq, nb0 + q);
             }
@@ -424,6 +431,7 @@ LaunchFn resident_cut_launcher(int R)
     case 32: return &launch_resident_cut<32>;
     case 64: return &launch_resident_cut<64>;
     case 128: return &launch_resident_cut<128>;
+    case 256: return &launch_resident_cut<256>;
     default: return nullptr;
     }
 }
@@ -435,6 +443,7 @@ LaunchFn resident_pipe_launcher(int R, bool diag)
     case 32: return diag ? &launch_resident_pipe<32, true> : &launch_resident_pipe<32, false>;
     case 64: return diag ? &launch_resident_pipe<64, true> : &launch_resident_pipe<64, false>;
     case 128: return diag ? &launch_resident_pipe<128, true> : &launch_resident_pipe<128, false>;
+    case 256: return diag ? nullptr : &launch_resident_pipe<256, false>;
     default: return nullptr;
     }
 }
