@@ -527,7 +527,9 @@ def test_pipelined_kernel_row_counts(ctx, N, K):
 
 LOWRANK = [(1, 256, 7, 16), (33, 256, 33, 16), (4097, 64, 1000, 16), (700, 128, 65, 5), (2000, 32, 12, 1),
            # Omega about square: prototypes resident, Omega streamed from L2 (k_omega_pipe)
-           (4097, 128, 256, 128), (65, 128, 1, 100), (900, 64, 70, 50), (31, 32, 10, 20)]
+           (4097, 128, 256, 128), (65, 128, 1, 100), (900, 64, 70, 50), (31, 32, 10, 20),
+           # row lengths off the power-of-two grid: the CUT variants of both kernels
+           (700, 200, 300, 16), (1000, 50, 64, 7), (500, 100, 256, 100), (333, 50, 40, 30), (2049, 126, 33, 126)]
 
 
 @pytest.mark.parametrize("case", LOWRANK, ids=lambda c: "n%d_d%d_k%d_m%d" % c)

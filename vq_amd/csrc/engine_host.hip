@@ -207,7 +207,7 @@ template <int R1>
 bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
                   const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
 {
-    if (m.D != (uint32_t)R1 || m.M > 16 || getenv("VQHIP_NO_RESIDENT")) return false;
+    if (m.R1 != (uint32_t)R1 || m.M > 16 || getenv("VQHIP_NO_RESIDENT")) return false;    // D < R1: the kernel's CUT variant
     constexpr int ROWF = R1 + 4;
     // p_k with chunks 1 and 2 swapped (see the kernel), zero padded to 16
     std::vector<float> Pp((size_t)m.K * 16, 0.0f);
@@ -240,7 +240,7 @@ template <int R>
 bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Om,
                      const std::vector<float> &P, const std::vector<float> &norms, const std::vector<uint32_t> &cls)
 {
-    if (m.D != (uint32_t)R || m.R2 > (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;   // Omega zero padded to R rows
+    if (m.R1 != (uint32_t)R || m.R2 > (uint32_t)R || getenv("VQHIP_NO_RESIDENT")) return false;   // Omega zero padded to R x R
     if ((size_t)res_tiles(m.K) * Geom<R>::TILE_BYTES > (size_t)RES_BYTES) return false;
     m.R2 = R;
     m.ldp = R;
@@ -256,7 +256,8 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
         for (int j = 0; j < NJ; ++j)
             for (int lane = 0; lane < 64; ++lane) {
                 const uint32_t row = 32u * t + (lane & 31), col = 4u * (2 * j + (lane >> 5));
-                if (row < m.M) std::memcpy(&img1[(((size_t)t * NJ + j) * 64 + lane) * 4], &Om[(size_t)row * m.D + col], 4 * sizeof(float));
+                for (uint32_t e = 0; e < 4; ++e)
+                    if (row < m.M && col + e < m.D) img1[(((size_t)t * NJ + j) * 64 + lane) * 4 + e] = Om[(size_t)row * m.D + col + e];
             }
     m.ngroups1 = 1;
     m.launch = omega_pipe_launcher(R);

@@ -20,7 +20,9 @@ namespace vq {
 //     chunks 1 and 2 of every row swapped (image chunk 2j+h <- chunk 2h+j of p_k).
 //   * the search is k_resident_pipe's (half_step / packed keys / exact re-measurement) at R = 16,
 //     distance squared and not rooted (helpers.rs:44).
-template <int R1, bool MATCHED, int NW = 8>
+// CUT (both kernels of this file): rows shorter than the padded length (any length, 4-byte aligned): the fetches are
+// cut at D in place before the projection reads them; the Omega images are zero there.
+template <int R1, bool MATCHED, bool CUT = false, int NW = 8>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineArgs a)
 {
     using Gs = Geom<16>;
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         }
     };
     // lane (n16, kg) loads 16 B of row n16 (group 0) and row 16 + n16 (group 1) per step: chunk 4j + kg
-    constexpr uint32_t row_bytes = R1 * 4u;
+    const uint32_t row_bytes = a.D * 4u;
     const uint32_t voff0 = (uint32_t)n16 * row_bytes + (uint32_t)kg * 16u;
     const uint32_t voff1 = voff0 + 16u * row_bytes;
     f32x4 xn[2][NJ];
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
     };
     auto fetch = [&](uint64_t bb) {
         const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R1), 0, (int)records(bb, row_bytes), 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             xn[0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff0 + j * 64, 0, 0));
@@ -102,6 +104,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
 
         // ---- projection: accA / accB = y of samples n16 / 16 + n16, rows 4 kg .. 4 kg + 3
         f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (CUT) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                xn[0][j] = mask_chunk(xn[0][j], (uint32_t)(4 * j + kg), a.D);
+                xn[1][j] = mask_chunk(xn[1][j], (uint32_t)(4 * j + kg), a.D);
+            }
+        }
         {
             f32x4 anext = *(const f32x4 *)om;
             static_for<0, NJ>([&](auto jj) {
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
 // ahead of its MFMAs.  No LDS stage, no barrier after the image load: waves run independently and
 // claim batches from the queue.  The projection's accumulators are the search stage's B fragment
 // (engine.h), the search is k_resident_pipe's, distance squared and not rooted (helpers.rs:44).
-template <int R, bool MATCHED, int NW = 8>
+template <int R, bool MATCHED, bool CUT = false, int NW = 8>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs a)
 {
     using Gs = Geom<R>;
@@ -231,7 +240,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
             nin = 0;
         }
     };
-    const uint32_t row_bytes = R * 4u;
+    const uint32_t row_bytes = a.D * 4u;
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
     f32x4 xn[R / 8];                                   // rows of the next batch, in flight
     uint32_t ln = 0u;
@@ -243,7 +252,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     };
     auto fetch = [&](uint64_t bb) {
         const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * R), 0, (int)records(bb, row_bytes), 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
 #pragma unroll
         for (int j = 0; j < R / 8; ++j)
             xn[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
@@ -265,6 +274,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         // ---- projection y = Omega x: 32 Omega rows per tile, A fragments from the ring; the accumulators of
         //      tile t are chunks 2(4t + g) + h of y, i.e. fragment entries 4t + g of the search stage
         f32x4 yf[R / 8];
+        if constexpr (CUT) {
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) xn[j] = mask_chunk(xn[j], (uint32_t)(2 * j + h), a.D);
+        }
         {
             f32x4 ring[DEPTH];
 #pragma unroll
@@ -337,7 +350,12 @@ hipError_t launch_lowrank(const EngineArgs &a, bool matched, hipStream_t st)
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    if (matched)
+    if (a.D < (uint32_t)R1) {
+        if (matched)
+            hipLaunchKernelGGL((k_lowrank_pipe<R1, true, true>), dim3(grid), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_lowrank_pipe<R1, false, true>), dim3(grid), dim3(512), 0, st, a);
+    } else if (matched)
         hipLaunchKernelGGL((k_lowrank_pipe<R1, true>), dim3(grid), dim3(512), 0, st, a);
     else
         hipLaunchKernelGGL((k_lowrank_pipe<R1, false>), dim3(grid), dim3(512), 0, st, a);
@@ -351,7 +369,12 @@ hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    if (matched)
+    if (a.D < (uint32_t)R) {
+        if (matched)
+            hipLaunchKernelGGL((k_omega_pipe<R, true, true>), dim3(grid), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_omega_pipe<R, false, true>), dim3(grid), dim3(512), 0, st, a);
+    } else if (matched)
         hipLaunchKernelGGL((k_omega_pipe<R, true>), dim3(grid), dim3(512), 0, st, a);
     else
         hipLaunchKernelGGL((k_omega_pipe<R, false>), dim3(grid), dim3(512), 0, st, a);
