@@ -491,6 +491,11 @@ def test_project_local(ctx, shape):
     want = np.stack([om[j].T @ (om[j] @ x.astype(np.float64)) for j, x in zip(win, X)])
     clear = (second - best) / np.maximum(best, 1e-300) > 1e-5              # near-tied winners may differ
     assert _rel_err(Y[clear], want[clear]) < 1e-5
+    assert ctx.last_kernel == "mfma_project_local"
+    ctx.set_kernel_policy(KERNEL_SCALAR)                                  # the scalar kernels stay the cross-check
+    assert _rel_err(ctx.project(X, PROJECT_LAMBDA)[clear], want[clear]) < 1e-5
+    assert ctx.last_kernel == "scalar_project"
+    ctx.set_kernel_policy(KERNEL_AUTO)
     with pytest.raises(VqhipError) as e:
         ctx.project(X, PROJECT_OMEGA)
     assert e.value.code == -5
@@ -498,6 +503,38 @@ def test_project_local(ctx, shape):
     with pytest.raises(VqhipError) as e:
         ctx.project(X, PROJECT_LAMBDA)
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("case", [(1, 128, 16, 4), (33, 30, 30, 3), (1000, 100, 20, 7), (4097, 128, 16, 64), (500, 250, 8, 5),
+                                  (65, 3, 2, 2), (3000, 64, 64, 1), (2500, 32, 5, 300)],
+                         ids=lambda c: "n%d_d%d_m%d_k%d" % c)
+def test_project_local_grouped_kernel(ctx, case):
+    """LGMLVQ::project on the matrix cores (lgmlvq.rs:372-393): samples grouped by winner on the device, every group
+    padded to whole batches of 32; groups of every size (empty ones, one that holds everything, more prototypes than
+    a batch has rows), row lengths off the grid, nothing written past N."""
+    import torch
+    from vq_amd import PROJECT_LAMBDA
+    N, D, M, K = case
+    rng = np.random.default_rng(N + D + M + K)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    Oms = (rng.uniform(-1, 1, size=(K, M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 2, D)).astype(np.float32)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    ctx.set_local_omegas(Oms)
+    Xd = torch.from_numpy(X).cuda()
+    Y = torch.full((N + 2, D), -7.0, dtype=torch.float32, device="cuda")
+    for _ in range(2):                                                    # twice: the scratch is reused
+        ctx.project_into(Xd[:N], Y[:N], PROJECT_LAMBDA)
+        torch.cuda.synchronize()
+    assert ctx.last_kernel == "mfma_project_local"
+    assert (Y[N:].cpu().numpy() == -7.0).all()
+    win, best, second = oracle.assign(X[:N], W, omega=Oms, threads=8)
+    om = Oms.astype(np.float64)
+    want = np.stack([om[j].T @ (om[j] @ x.astype(np.float64)) for j, x in zip(win, X[:N])])
+    clear = (second - best) / np.maximum(best, 1e-300) > 1e-5
+    assert clear.mean() > 0.9
+    assert _rel_err(Y[:N].cpu().numpy()[clear], want[clear]) < 1e-5
 
 
 @pytest.mark.parametrize("K", [256, 20], ids=["pipe_k256", "staged_k20"])

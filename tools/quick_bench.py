@@ -44,3 +44,13 @@ if len(sys.argv) > 3 and sys.argv[3] == "project" and cfg.omega == "global":
         ev[1].record(); torch.cuda.synchronize()
         ms = ev[0].elapsed_time(ev[1]) / K
         print(f"{name} {nm} kernel={ctx.last_kernel} N={N} ms={ms:.3f} samples/s={N/ms*1e3:.4g} TFLOP/s={N*fl/ms/1e9:.1f} GB/s={N*(cfg.D+width)*4/ms/1e6:.0f}")
+if len(sys.argv) > 3 and sys.argv[3] == "project" and cfg.omega == "local":
+    from vq_amd import PROJECT_LAMBDA
+    Y = torch.empty((N, cfg.D), dtype=torch.float32, device="cuda")
+    for _ in range(2): ctx.project_into(X, Y, PROJECT_LAMBDA)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(K): ctx.project_into(X, Y, PROJECT_LAMBDA)
+    ev[1].record(); torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / K
+    print(f"{name} project(Lambda_j of the winner) kernel={ctx.last_kernel} N={N} ms={ms:.3f} samples/s={N/ms*1e3:.4g}")

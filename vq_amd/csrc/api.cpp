@@ -53,6 +53,7 @@ struct vqhip_ctx {
     bool engine_tried = false;
     std::string engine_why;
     ProjectModel *proj_omega = nullptr, *proj_lambda = nullptr;   // matrix-core projections (global Omega)
+    LocalProjectModel *proj_local = nullptr;                      // LGMLVQ::project (local Omegas)
     bool proj_tried = false;
 
     Staging st[2];
@@ -87,7 +88,9 @@ void drop_engine(vqhip_ctx *c)
     c->engine_why.clear();
     project_free(c->proj_omega);
     project_free(c->proj_lambda);
+    local_project_free(c->proj_local);
     c->proj_omega = c->proj_lambda = nullptr;
+    c->proj_local = nullptr;
     c->proj_tried = false;
 }
 
@@ -169,7 +172,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
     int rc = prepare_engine(c);
     if (rc != VQHIP_OK) return rc;
 
-    if (c->engine) {
+    if (c->engine && c->policy != VQHIP_KERNEL_SCALAR) {      // (an engine built before the policy was set to scalar stays unused)
         c->last_kernel = engine_name(c->engine);
         HIPCHK(c, engine_assign(c->engine, dX, N, dy, out, s));
         return VQHIP_OK;
@@ -316,9 +319,14 @@ int check_project(vqhip_ctx *c, int which)
 // multiplies every sample by it, gmlvq.rs:357-366) for the matrix-core projection kernel.
 int prepare_project(vqhip_ctx *c)
 {
-    if (c->proj_tried || c->policy == VQHIP_KERNEL_SCALAR || c->omega_kind != OMEGA_GLOBAL) return VQHIP_OK;
+    if (c->proj_tried || c->policy == VQHIP_KERNEL_SCALAR) return VQHIP_OK;
     c->proj_tried = true;
     hipError_t herr = hipSuccess;
+    if (c->omega_kind == OMEGA_LOCAL) {                    // Lambda_j of every prototype (lgmlvq.rs:383-384)
+        c->proj_local = local_project_build(c->hOm, c->K, c->M, c->D, herr);
+        if (herr != hipSuccess) return c->fail_hip(herr, "local_project_build");
+        return VQHIP_OK;
+    }
     c->proj_omega = project_build(c->hOm, c->M, c->D, herr);
     if (herr != hipSuccess) return c->fail_hip(herr, "project_build");
     if (!c->proj_omega) return VQHIP_OK;
@@ -349,6 +357,31 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
             HIPCHK(c, project_run(pm, dX, N, dY, ldy, s));
             return VQHIP_OK;
         }
+    }
+    if (c->omega_kind == OMEGA_LOCAL && c->policy != VQHIP_KERNEL_SCALAR && c->proj_local && ((uintptr_t)dY & 3) == 0 &&
+        ((uintptr_t)dX & 3) == 0) {
+        // winners of a chunk of rows, then the chunk grouped by winner and projected on the matrix cores
+        const LocalProjectModel *pm = c->proj_local;
+        const uint64_t chunk = std::min<uint64_t>(N, std::min<uint64_t>(local_project_max_rows(pm), 4ull << 20));
+        const size_t need = (size_t)chunk + local_project_scratch_words(pm, chunk);
+        if (c->dProj_cap < need) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            (void)hipFree(c->dProj);
+            c->dProj = nullptr;
+            c->dProj_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->dProj, need * sizeof(float)));
+            c->dProj_cap = need;
+        }
+        uint32_t *dwin = (uint32_t *)c->dProj;
+        if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
+        for (uint64_t off = 0; off < N; off += chunk) {
+            const uint64_t n = std::min(chunk, N - off);
+            rc = run_device(c, dX + off * c->D, n, nullptr, Outputs{dwin, nullptr, nullptr, nullptr}, s);
+            if (rc != VQHIP_OK) return rc;
+            HIPCHK(c, local_project_run(pm, dX + off * c->D, n, dwin, dwin + chunk, dY + off * c->D, s));
+        }
+        c->last_kernel = "mfma_project_local";
+        return scratch_release(c, s);
     }
     c->last_kernel = "scalar_project";
     if (c->omega_kind == OMEGA_GLOBAL && which == VQHIP_PROJECT_OMEGA) {          // liramlvq.rs:429-446
@@ -382,6 +415,7 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
             HIPCHK(c, launch_project_local(x, n, c->D, c->dOm, c->M, dwin, dT, y, s));
         }
     }
+    c->last_kernel = "scalar_project";                    // (the winner search in between has set its own name)
     return scratch_release(c, s);
 }
 

@@ -2,6 +2,7 @@
 // src/liramlvq/liramlvq.rs:401-446.  Kernel and its host-side model (tile image of Omega or Lambda in LDS).
 #include <algorithm>
 #include <cstdlib>
+#include <thread>
 
 #include "mfma_device.h"
 #include "mfma_images.h"
@@ -223,6 +224,277 @@ hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------ LGMLVQ::project (src/lgmlvq/lgmlvq.rs:372-393)
+// Y[i] = Lambda_j x_i with j the sample's nearest prototype (the search has run; `win` holds j).  The samples
+// are grouped by j on the device (count, plan, scatter: a counting sort into slots of 32, every group padded to
+// whole batches), then every batch of 32 slots is one k_project batch against ITS matrix: rows gathered through
+// the slot table, the A fragments of Lambda_j streamed from L2 in the 1 KiB piece layout of k_omega_pipe
+// (K matrices do not fit LDS: 4 MiB at config 5), results scattered back to the samples' own rows.
+// Lambda_j = Omega_j^T Omega_j is built once per model in f64 and rounded to f32, as the reference builds it
+// before multiplying (lgmlvq.rs:384-387).
+constexpr uint32_t GROUP_MAX_K = 4096;                 // LDS histograms of the grouping kernels
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(256) k_group_count(const uint32_t *__restrict__ win, uint32_t n, uint32_t K, uint32_t *counts)
+{
+    __shared__ uint32_t hist[GROUP_MAX_K];
+    for (uint32_t j = threadIdx.x; j < K; j += 256) hist[j] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t j = win[i];
+        if (j < K) atomicAdd(&hist[j], 1u);
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < K; j += 256)
+        if (hist[j]) atomicAdd(&counts[j], hist[j]);
+}
+
+// One workgroup.  starts[j] = first slot of group j (a multiple of 32), batch_j[b] = matrix of batch b or NO_SLOT
+// for the unused batches up to `cap`; counts[] is cleared: the scatter uses it as the groups' cursors.
+__global__ void __launch_bounds__(256) k_group_plan(uint32_t *counts, uint32_t K, uint32_t *starts, uint32_t *batch_j, uint32_t cap)
+{
+    __shared__ uint32_t first[GROUP_MAX_K + 1];
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t j = 0; j < K; ++j) {
+            first[j] = run;
+            run += (counts[j] + 31u) / 32u;
+        }
+        first[K] = run;
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < K; ++j)
+        for (uint32_t b = first[j] + threadIdx.x; b < first[j + 1]; b += 256) batch_j[b] = j;
+    for (uint32_t b = first[K] + threadIdx.x; b < cap; b += 256) batch_j[b] = NO_SLOT;
+    for (uint32_t j = threadIdx.x; j < K; j += 256) {
+        starts[j] = first[j] * 32u;
+        counts[j] = 0u;
+    }
+}
+
+// slots[starts[j] + position] = sample, positions handed out per workgroup tile (one global atomic per tile and
+// group, ranks inside the tile from the LDS histogram).  The order inside a group is whatever the atomics give;
+// every sample's result goes back to its own row, so the output does not depend on it.
+__global__ void __launch_bounds__(256) k_group_scatter(const uint32_t *__restrict__ win, uint32_t n, uint32_t K,
+                                                       const uint32_t *__restrict__ starts, uint32_t *cursor, uint32_t *slots)
+{
+    constexpr uint32_t PER = 8, TILE = 256 * PER;
+    __shared__ uint32_t hist[GROUP_MAX_K], base[GROUP_MAX_K];
+    for (uint64_t t0 = (uint64_t)blockIdx.x * TILE; t0 < n; t0 += (uint64_t)gridDim.x * TILE) {
+        for (uint32_t j = threadIdx.x; j < K; j += 256) hist[j] = 0;
+        __syncthreads();
+        uint32_t jv[PER], rank[PER];
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) {
+            const uint64_t i = t0 + q * 256 + threadIdx.x;
+            jv[q] = i < n ? win[i] : NO_SLOT;
+            rank[q] = jv[q] < K ? atomicAdd(&hist[jv[q]], 1u) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < K; j += 256)
+            if (hist[j]) base[j] = starts[j] + atomicAdd(&cursor[j], hist[j]);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q)
+            if (jv[q] < K) slots[base[jv[q]] + rank[q]] = (uint32_t)(t0 + q * 256 + threadIdx.x);
+        __syncthreads();
+    }
+}
+
+struct LocalProjectArgs {
+    const float *X;           // n x D, n * D * 4 < 2^32
+    uint32_t n, D;
+    const float *pieces;      // K matrices of (R/32) * (R/8) pieces of 1 KiB
+    const uint32_t *slots;    // 32 per batch: sample or NO_SLOT
+    const uint32_t *batch_j;  // matrix of the batch or NO_SLOT
+    uint32_t nbatches;
+    float *Y;                 // n x D
+};
+
+template <int R, int NW = 4>
+__global__ void __launch_bounds__(NW * 64) k_project_local(const LocalProjectArgs a)
+{
+    constexpr int NT = R / 32, NJ = R / 8, NSTEP = NT * NJ;
+    constexpr int DEPTH = 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t row_bytes = a.D * 4u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)a.X, 0, (int)(a.n * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)a.Y, 0, (int)(a.n * row_bytes), 0x00020000);
+    const bool vec_store = (a.D & 3u) == 0u && ((uintptr_t)a.Y & 15u) == 0u;
+    const uint32_t om_off = (uint32_t)lane * 16u;
+
+    for (uint32_t b = blockIdx.x * NW + wave; b < a.nbatches; b += gridDim.x * NW) {
+        const uint32_t mat = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.batch_j[b]);
+        if (mat == NO_SLOT) continue;
+        const uint32_t id = a.slots[(size_t)b * 32 + s_col];
+        const bool valid = id < a.n;
+        // an empty slot computes on row 0: column s of the product depends on sample s alone, and it is not stored
+        const uint32_t xoff = (valid ? id : 0u) * row_bytes + (uint32_t)h * 16u;
+        f32x4 x[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) x[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xoff + j * 32, 0, 0));
+        const __amdgpu_buffer_rsrc_t rom =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.pieces + (size_t)mat * NSTEP * 256), 0, NSTEP * 1024, 0x00020000);
+        auto piece = [&](int i) {
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, i * 1024, 0));
+        };
+        f32x4 ring[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) ring[i] = piece(i);
+        // what lies behind a row's D values is the next row or the end of the buffer
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) x[j] = mask_chunk(x[j], (uint32_t)(2 * j + h), a.D);
+        const uint32_t yoff = (valid ? id : 0u) * row_bytes;
+        static_for<0, NT>([&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            static_for<0, NJ>([&](auto jj) {
+                constexpr int j = decltype(jj)::value, i = t * NJ + j;
+                const f32x4 av = ring[i % DEPTH];
+                if constexpr (i + DEPTH < NSTEP) ring[i % DEPTH] = piece(i + DEPTH);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], x[j][e], acc, 0, 0, 0);
+            });
+            if (valid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t col = 32u * t + 8u * g + 4u * h;
+                    if (vec_store && col + 4u <= a.D) {
+                        const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, yoff + col * 4u, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float val = acc[4 * g + e];
+                            if (col + e < a.D)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ry, yoff + (col + e) * 4u, 0, 0);
+                        }
+                    }
+                }
+            }
+        });
+    }
+}
+
+struct LocalProjectModel {
+    uint32_t K = 0, D = 0, R = 0;
+    float *pieces = nullptr;
+    void (*launch)(const LocalProjectArgs &, unsigned, hipStream_t) = nullptr;
+};
+
+namespace {
+template <int R>
+void launch_project_local_t(const LocalProjectArgs &a, unsigned grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_project_local<R>), dim3(grid), dim3(256), 0, st, a);
+}
+
+template <int R>
+bool bind_local_project(LocalProjectModel &m, std::vector<float> &pieces, const std::vector<float> &Oms, uint32_t M)
+{
+    if (m.D > (uint32_t)R || (R > 32 && m.D <= (uint32_t)R / 2)) return false;
+    constexpr int NT = R / 32, NJ = R / 8;
+    const uint32_t D = m.D;
+    const size_t per = (size_t)NT * NJ * 256;
+    pieces.assign((size_t)m.K * per, 0.0f);
+    const unsigned nthreads = std::max(1u, std::min(16u, std::min(m.K, std::thread::hardware_concurrency())));
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nthreads; ++w)
+        pool.emplace_back([&, w] {
+            std::vector<double> lam((size_t)D * D);
+            for (uint32_t k = w; k < m.K; k += nthreads) {
+                const float *om = &Oms[(size_t)k * M * D];
+                std::fill(lam.begin(), lam.end(), 0.0);
+                for (uint32_t r = 0; r < M; ++r)
+                    for (uint32_t i = 0; i < D; ++i) {
+                        const double oi = om[(size_t)r * D + i];
+                        for (uint32_t j = i; j < D; ++j) lam[(size_t)i * D + j] += oi * (double)om[(size_t)r * D + j];
+                    }
+                // piece (t, j), lane (row, h) = Lambda[32 t + row][4 (2 j + h) .. + 3]
+                float *out = &pieces[(size_t)k * per];
+                for (int t = 0; t < NT; ++t)
+                    for (int j = 0; j < NJ; ++j)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const uint32_t row = 32u * t + (lane & 31), col = 4u * (2 * j + (lane >> 5));
+                            for (uint32_t e = 0; e < 4; ++e)
+                                if (row < D && col + e < D) {
+                                    const uint32_t lo = std::min(row, col + e), hi = std::max(row, col + e);
+                                    out[(((size_t)t * NJ + j) * 64 + lane) * 4 + e] = (float)lam[(size_t)lo * D + hi];
+                                }
+                        }
+            }
+        });
+    for (std::thread &t : pool) t.join();
+    m.R = R;
+    m.launch = &launch_project_local_t<R>;
+    return true;
+}
+}  // namespace
+
+LocalProjectModel *local_project_build(const std::vector<float> &Oms, uint32_t K, uint32_t M, uint32_t D, hipError_t &herr)
+{
+    herr = hipSuccess;
+    if (K == 0 || K > GROUP_MAX_K || D > 256 || (size_t)K * 256 * 256 * 4 > ((size_t)1 << 30)) return nullptr;
+    LocalProjectModel m;
+    m.K = K;
+    m.D = D;
+    std::vector<float> pieces;
+    if (!(bind_local_project<32>(m, pieces, Oms, M) || bind_local_project<64>(m, pieces, Oms, M) ||
+          bind_local_project<128>(m, pieces, Oms, M) || bind_local_project<256>(m, pieces, Oms, M)))
+        return nullptr;
+    LocalProjectModel *out = new LocalProjectModel(m);
+    herr = to_device(&out->pieces, pieces);
+    if (herr != hipSuccess) {
+        local_project_free(out);
+        return nullptr;
+    }
+    return out;
+}
+
+void local_project_free(LocalProjectModel *m)
+{
+    if (!m) return;
+    (void)hipFree(m->pieces);
+    delete m;
+}
+
+// rows one call takes (32-bit byte offsets into X and Y) and the u32 words of scratch it needs for them
+uint64_t local_project_max_rows(const LocalProjectModel *m) { return 0xFFFFFFFFull / (m->D * 4ull); }
+
+size_t local_project_scratch_words(const LocalProjectModel *m, uint64_t n)
+{
+    const size_t cap = (size_t)((n + 31) / 32) + m->K;
+    return cap * 32 + cap + 2 * (size_t)m->K;
+}
+
+// dwin: the n winners (already computed on `s`); scratch: local_project_scratch_words(m, n) words
+hipError_t local_project_run(const LocalProjectModel *m, const float *dX, uint64_t n, const uint32_t *dwin, uint32_t *scratch,
+                             float *dY, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    if (n > local_project_max_rows(m)) return hipErrorInvalidValue;
+    const uint32_t cap = (uint32_t)((n + 31) / 32) + m->K;
+    uint32_t *slots = scratch, *batch_j = slots + (size_t)cap * 32, *counts = batch_j + cap, *starts = counts + m->K;
+    hipError_t e = hipMemsetAsync(slots, 0xFF, (size_t)cap * 32 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(counts, 0, m->K * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 2047) / 2048, 1024);
+    hipLaunchKernelGGL(k_group_count, dim3(grid), dim3(256), 0, s, dwin, (uint32_t)n, m->K, counts);
+    hipLaunchKernelGGL(k_group_plan, dim3(1), dim3(256), 0, s, counts, m->K, starts, batch_j, cap);
+    hipLaunchKernelGGL(k_group_scatter, dim3(grid), dim3(256), 0, s, dwin, (uint32_t)n, m->K, starts, counts, slots);
+    LocalProjectArgs a;
+    a.X = dX; a.n = (uint32_t)n; a.D = m->D;
+    a.pieces = m->pieces; a.slots = slots; a.batch_j = batch_j; a.nbatches = cap;
+    a.Y = dY;
+    m->launch(a, (unsigned)std::min<uint32_t>((cap + 3) / 4, 2048), s);
+    return hipGetLastError();
 }
 
 }  // namespace vq

@@ -80,6 +80,15 @@ ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t
 void project_free(ProjectModel *m);
 hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float *dY, uint32_t ldy, hipStream_t s);
 
+// LGMLVQ::project on the matrix cores (kernels_project.hip): samples grouped by winner, Lambda_j from L2
+struct LocalProjectModel;
+LocalProjectModel *local_project_build(const std::vector<float> &Oms, uint32_t K, uint32_t M, uint32_t D, hipError_t &herr);
+void local_project_free(LocalProjectModel *m);
+uint64_t local_project_max_rows(const LocalProjectModel *m);
+size_t local_project_scratch_words(const LocalProjectModel *m, uint64_t n);
+hipError_t local_project_run(const LocalProjectModel *m, const float *dX, uint64_t n, const uint32_t *dwin, uint32_t *scratch,
+                             float *dY, hipStream_t s);
+
 // ---------------------------------------------------------------- synth (synth.hip)
 hipError_t launch_synth_fill(float *dout, uint64_t count, uint64_t first, uint64_t seed, uint32_t stream_id,
                              float scale, const float *dbase, uint64_t base_len, hipStream_t s);
