@@ -775,7 +775,9 @@ def test_row_lengths_that_are_not_multiples_of_four(ctx, D):
 
 
 @pytest.mark.parametrize("case", [(2000, 300, 50), (1500, 784, 10), (700, 257, 128), (333, 1000, 33), (65, 2049, 3), (4097, 512, 64),
-                                  (500, 300, 200), (300, 513, 256)],
+                                  (500, 300, 200), (300, 513, 256),
+                                  # more than 256 prototypes: groups of 8 tiles, the rows fetched again per group
+                                  (400, 300, 257), (300, 784, 1000), (200, 400, 600)],
                          ids=lambda c: "n%d_d%d_k%d" % c)
 def test_long_rows(ctx, case):
     """Rows above 256 values (k_long: the reduction in chunks of 128, candidates re-measured in a second sweep):

@@ -8,6 +8,9 @@ M = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 4_000_000
 rng = np.random.default_rng(0)
 ctx = Context(0)
+if os.environ.get("SHAPE_BENCH_SCALAR"):
+    from vq_amd import KERNEL_SCALAR
+    ctx.set_kernel_policy(KERNEL_SCALAR)
 ctx.set_prototypes(rng.uniform(-1, 1, size=(K, D)).astype(np.float32))
 if M:
     ctx.set_omega((rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3)).astype(np.float32))

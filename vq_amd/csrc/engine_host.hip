@@ -118,30 +118,32 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     return true;
 }
 
-// Rows above 256 values, at most 256 prototypes: k_long.  img1 = A-fragment pieces of -2 W, one 1 KiB piece per
-// (chunk of 128 or 64 values, tile of 32 prototypes, step): lane (row, h) of step j holds values 4 (2 j + h) .. + 3 of the
-// chunk; img2 = the tiles' tails (||w_k||^2 / class ids); plain rows padded to whole chunks.
+// Rows above 256 values: k_long.  img1 = A-fragment pieces of -2 W, one 1 KiB piece per (group of 8 tiles when there
+// are more than 8, chunk of 128 or 64 values, tile of 32 prototypes, step): lane (row, h) of step j holds values
+// 4 (2 j + h) .. + 3 of the chunk; img2 = the tiles' tails (||w_k||^2 / class ids); plain rows padded to whole chunks.
 bool bind_long(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &W,
                const std::vector<float> &norms, const std::vector<uint32_t> &cls)
 {
-    if (m.D <= 256) return false;
-    const uint32_t rt = res_tiles(m.K), tiles = rt <= 2 ? rt : (rt <= 4 ? 4 : 8);
+    if (m.D <= 256 || m.K > 4096) return false;
+    const uint32_t rt = res_tiles(m.K), tiles = rt <= 2 ? rt : (rt <= 4 ? 4 : 8), groups = (rt + tiles - 1) / tiles;
     const uint32_t steps = tiles <= 2 ? 16 : 8, chunk = steps * 8;     // as in the kernel: 128-value chunks up to 2 tiles, else 64
     const uint32_t NC = (m.D + chunk - 1) / chunk;
     const LaunchFn fn = long_launcher((int)tiles);
     if (!fn) return false;
-    img1.assign((size_t)NC * tiles * steps * 64 * 4, 0.0f);
-    for (uint32_t c = 0; c < NC; ++c)
-        for (uint32_t t = 0; t < tiles; ++t)
-            for (uint32_t j = 0; j < steps; ++j)
-                for (uint32_t lane = 0; lane < 64; ++lane) {
-                    const uint32_t k = 32 * t + (lane & 31), d0 = chunk * c + 4 * (2 * j + (lane >> 5));
-                    float *dst = &img1[((((size_t)c * tiles + t) * steps + j) * 64 + lane) * 4];
-                    for (uint32_t e = 0; e < 4; ++e)
-                        if (k < m.K && d0 + e < m.D) dst[e] = -2.0f * W[(size_t)k * m.D + d0 + e];
-                }
-    img2.assign((size_t)tiles * TAIL_FLOATS, 0.0f);
-    for (uint32_t t = 0; t < tiles; ++t)
+    img1.assign((size_t)groups * NC * tiles * steps * 64 * 4, 0.0f);
+    for (uint32_t g = 0; g < groups; ++g)
+        for (uint32_t c = 0; c < NC; ++c)
+            for (uint32_t t = 0; t < tiles; ++t)
+                for (uint32_t j = 0; j < steps; ++j)
+                    for (uint32_t lane = 0; lane < 64; ++lane) {
+                        const uint32_t k = 32 * (g * tiles + t) + (lane & 31), d0 = chunk * c + 4 * (2 * j + (lane >> 5));
+                        float *dst = &img1[(((((size_t)g * NC + c) * tiles + t) * steps + j) * 64 + lane) * 4];
+                        for (uint32_t e = 0; e < 4; ++e)
+                            if (k < m.K && d0 + e < m.D) dst[e] = -2.0f * W[(size_t)k * m.D + d0 + e];
+                    }
+    m.ngroups1 = groups;
+    img2.assign((size_t)groups * tiles * TAIL_FLOATS, 0.0f);
+    for (uint32_t t = 0; t < groups * tiles; ++t)
         for (uint32_t r = 0; r < 32; ++r) {
             const uint32_t k = 32 * t + r;
             img2[(size_t)t * TAIL_FLOATS + r] = k < m.K ? norms[k] : PAD_SCORE;
@@ -297,9 +299,9 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                           hipError_t &herr)
 {
     herr = hipSuccess;
-    if (D > 256 && !(((omega_kind == OMEGA_NONE && K <= 256) || (omega_kind == OMEGA_GLOBAL && M <= 128)) && D <= 65536 &&
+    if (D > 256 && !(((omega_kind == OMEGA_NONE && K <= 4096) || (omega_kind == OMEGA_GLOBAL && M <= 128)) && D <= 65536 &&
                      !getenv("VQHIP_NO_LONG"))) {
-        why = "sample length above 256 (served for Euclidean models with at most 256 prototypes and for a global Omega of at most 128 rows)";
+        why = "sample length above 256 (served for Euclidean models with at most 4096 prototypes and for a global Omega of at most 128 rows)";
         return nullptr;
     }
     if (omega_kind != OMEGA_NONE && M > 256) {

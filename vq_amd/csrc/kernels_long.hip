@@ -1,5 +1,6 @@
 // Euclidean models with rows longer than 256 values (VQ / LVQ / GLVQ: src/helpers.rs:11-24, 55-77, 91-132) on the
-// matrix cores, for up to 256 prototypes.  The reduction runs over chunks of 128 (more than 64 prototypes: 64) values:
+// matrix cores.  Up to 256 prototypes the reduction runs once, over chunks of 128 (more than 64 prototypes: 64) values;
+// more prototypes are worked in groups of 256 (8 tiles), the rows fetched once more per group:
 //   pass 1  every chunk of the wave's 32 rows is fetched once and multiplied into ALL the tiles' accumulators
 //           (NT x 16 registers stay live across the chunks); the prototypes' A fragments stream from L2 through a
 //           register ring, one 1 KiB piece per (chunk, tile, step), so there is no LDS stage and no barrier;
@@ -23,9 +24,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
     static_assert(NJ % DEPTH == 0, "ring slots are compile-time");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
-    const uint32_t NC = (a.D + CHUNK - 1) / CHUNK, npieces = NC * NT * NJ;
+    const uint32_t NC = (a.D + CHUNK - 1) / CHUNK, NG = a.ngroups1, npieces = NG * NC * NT * NJ;
 
-    // A fragments: piece p = (chunk * NT + tile) * NJ + step, this lane's 16 bytes at p * 1024 + lane * 16
+    // A fragments: piece p = ((group * NC + chunk) * NT + tile) * NJ + step, this lane's 16 bytes at p * 1024 + lane * 16
     const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, (int)(npieces * 1024u), 0x00020000);
     const uint32_t om_off = (uint32_t)lane * 16u;
     auto piece = [&](uint32_t p) {                     // past the last piece: range-check zeros, never used
@@ -119,25 +120,31 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
             const uint64_t bnext = q + 1 < BLOCK ? b + 1 : nb0;
             const uint32_t label = ln[q];
 
-            // ---- pass 1: all tiles' scores, accumulators start at the ||w_k||^2 column
+            f32x4 ring[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = piece((uint32_t)i);
+            uint32_t pnext = DEPTH;                    // next piece to request: the ring runs on across the groups
+            float ss = 0.0f;
+            Keys2 ku;
+            KeysM km;
+            for (uint32_t grp = 0; grp < NG; ++grp) {
+            // ---- pass 1: all tiles' scores of this group, accumulators start at the ||w_k||^2 column
+            const float *gtails = tails + (size_t)grp * NT * TAIL_FLOATS;
             f32x16 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 ci = *(const f32x4 *)(tails + t * TAIL_FLOATS + 8 * g + 4 * h);
+                    const f32x4 ci = *(const f32x4 *)(gtails + t * TAIL_FLOATS + 8 * g + 4 * h);
                     acc[t][4 * g + 0] = ci[0]; acc[t][4 * g + 1] = ci[1]; acc[t][4 * g + 2] = ci[2]; acc[t][4 * g + 3] = ci[3];
                 }
-            f32x4 ring[DEPTH];
-#pragma unroll
-            for (int i = 0; i < DEPTH; ++i) ring[i] = piece((uint32_t)i);
-            uint32_t pnext = DEPTH;                    // next piece to request
-            float ss = 0.0f;
             for_chunks(b, [&](const f32x4 (&xs)[NJ], uint32_t) {
+                if (grp == 0) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ss = fmaf(xs[j][e], xs[j][e], ss);
+                        for (int e = 0; e < 4; ++e) ss = fmaf(xs[j][e], xs[j][e], ss);
+                }
                 static_for<0, NT>([&](auto tt) {
                     static_for<0, NJ>([&](auto jj) {
                         constexpr int j = decltype(jj)::value;
@@ -149,21 +156,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                     });
                 });
             });
-            ss += xor32(ss);
-            bool unsafe = !(ss < a.ss_limit);          // NaN / INF / huge rows: exact scan below
+            if (grp + 1 < NG) fetch_x(xa, b, 0);       // the next group walks the rows again
 
             // ---- screening
-            Keys2 ku;
-            KeysM km;
             static_for<0, NT>([&](auto tt) {
                 constexpr int t = decltype(tt)::value;
+                const uint32_t tile = grp * NT + (uint32_t)t;
                 if constexpr (!MATCHED) {
                     const Keys2 before = ku;
                     screen16<1>(acc[t], ku);
-                    settle_tiles(ku, before, (uint32_t)t);
+                    settle_tiles(ku, before, tile);
                 } else {
                     const KeysM before = km;
-                    const uint32_t *tcls = (const uint32_t *)(tails + t * TAIL_FLOATS) + 32 + 4 * h;
+                    const uint32_t *tcls = (const uint32_t *)(gtails + t * TAIL_FLOATS) + 32 + 4 * h;
                     asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");   // asm readers of fresh MFMA results: wait states by hand
                     static_for<0, 16>([&](auto oo) {
                         constexpr int o = decltype(oo)::value;
@@ -173,10 +178,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                         km.p = kmin(km.p, kp);
                         km.n = kmin(km.n, kn);
                     });
-                    km.tp = km.p != before.p ? (uint32_t)t : before.tp;
-                    km.tn = km.n != before.n ? (uint32_t)t : before.tn;
+                    km.tp = km.p != before.p ? tile : before.tp;
+                    km.tn = km.n != before.n ? tile : before.tn;
                 }
             });
+            }
+            ss += xor32(ss);
+            bool unsafe = !(ss < a.ss_limit);          // NaN / INF / huge rows: exact scan below
 
             // ---- the lane pair agrees on two candidates; pass 2 re-measures them
             uint32_t c0, c1;                           // unlabelled: best two; labelled: best matching, best non-matching
