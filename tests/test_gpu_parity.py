@@ -820,6 +820,55 @@ def test_long_rows(ctx, case):
         assert rep.ok, f"{case} matching={matching}: {rep}"
 
 
+@pytest.mark.parametrize("case", [(600, 784, 10, 10), (300, 300, 3, 40), (200, 512, 5, 33), (65, 1000, 1, 3), (500, 257, 37, 2), (150, 400, 2, 100)],
+                         ids=lambda c: "n%d_d%d_k%d_m%d" % c)
+def test_long_rows_local(ctx, case):
+    """LGMLVQ over rows above 256 values (k_local_long: the tiles of all Omega_j stacked, groups of up to 4 tiles, the
+    rows walked once per group): plain and matched against the oracle, NaN / INF rows, nothing written past N."""
+    import torch
+    N, D, K, M = case
+    rng = np.random.default_rng(N + D + K + M)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    Oms = (rng.uniform(-1, 1, size=(K, M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 2, D)).astype(np.float32)
+    X[5 % N, D - 1] = np.nan
+    X[40 % N, 0] = np.inf
+    o = oracle.assign(X[:N], W, omega=Oms, threads=8)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    ctx.set_local_omegas(Oms)
+    Xd = torch.from_numpy(X).cuda()
+    idx = torch.full((N + 2,), -7, dtype=torch.int32, device="cuda")
+    dist = torch.full((N + 2,), -7.0, dtype=torch.float32, device="cuda")
+    ctx.assign_into(Xd[:N], idx[:N], dist[:N])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "mfma_local_long"
+    assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()
+    gi, gd = idx[:N].cpu().numpy(), dist[:N].cpu().numpy()
+    fin = np.isfinite(gd)
+    rep = parity.compare(gi[fin], gd[fin], o[0][fin], o[1][fin], o[2][fin], atol=2e-6)
+    assert rep.ok, str(rep)
+    assert not fin[5 % N] and gi[5 % N] == 0 and not fin[40 % N] and gi[40 % N] == 0
+    assert fin.sum() >= N - 2
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    ctx.set_labels(cls)
+    jp, dp, jn, dn = ctx.assign_matched(X[:N], y)
+    assert ctx.last_kernel == "mfma_local_long"
+    for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+        om = oracle.assign(X[:N], W, omega=Oms, proto_cls=cls, labels=y, matching=matching, threads=8)
+        f2 = np.isfinite(d) | ~np.isfinite(om[1])
+        f2 &= fin | ~np.isfinite(om[1])
+        rep = parity.compare(j[f2], d[f2], om[0][f2], om[1][f2], om[2][f2], atol=2e-6)
+        assert rep.ok, f"{case} matching={matching}: {rep}"
+    ctx.set_kernel_policy(KERNEL_SCALAR)                                  # the scalar kernel agrees
+    si, sd = ctx.assign(X[:N])
+    assert ctx.last_kernel == "scalar"
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    same = fin & np.isfinite(sd)
+    assert (si[same] == gi[same]).mean() > 0.999
+
+
 @pytest.mark.parametrize("case", [(600, 784, 40, 16), (300, 300, 100, 40), (200, 512, 10, 128), (40, 1000, 257, 3)],
                          ids=lambda c: "n%d_d%d_k%d_m%d" % c)
 def test_long_rows_omega(ctx, case):

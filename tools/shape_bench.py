@@ -12,7 +12,9 @@ if os.environ.get("SHAPE_BENCH_SCALAR"):
     from vq_amd import KERNEL_SCALAR
     ctx.set_kernel_policy(KERNEL_SCALAR)
 ctx.set_prototypes(rng.uniform(-1, 1, size=(K, D)).astype(np.float32))
-if M:
+if M and os.environ.get("SHAPE_BENCH_LOCAL"):
+    ctx.set_local_omegas((rng.uniform(-1, 1, size=(K, M, D)) / np.sqrt(M * D / 3)).astype(np.float32))
+elif M:
     ctx.set_omega((rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3)).astype(np.float32))
 X = torch.empty(N, D, device="cuda").uniform_(-1, 1)
 idx = torch.empty(N, dtype=torch.int32, device="cuda"); dist = torch.empty(N, dtype=torch.float32, device="cuda")

@@ -268,6 +268,46 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     return true;
 }
 
+// LGMLVQ over rows above 256 values: k_local_long.  The tiles of all prototypes stacked (every Omega_j padded to
+// whole tiles), img1 = their A-fragment pieces per (group of tiles, chunk of 64 values, tile, step) as in bind_long,
+// img2 = the tiles' init columns -(Omega_j w_j).
+bool bind_local_long(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &Oms,
+                     const std::vector<float> &negp)
+{
+    if (m.D <= 256) return false;
+    const uint32_t tpp = (m.M + 31) / 32, total = m.K * tpp;
+    const uint32_t tiles = total <= 2 ? total : 4, groups = (total + tiles - 1) / tiles;   // (8 tiles of accumulators spill here)
+    const uint32_t steps = 8, chunk = 64, NC = (m.D + chunk - 1) / chunk;
+    const LaunchFn fn = local_long_launcher((int)tiles);
+    if (!fn) return false;
+    img1.assign((size_t)groups * NC * tiles * steps * 64 * 4, 0.0f);
+    for (uint32_t g = 0; g < groups; ++g)
+        for (uint32_t c = 0; c < NC; ++c)
+            for (uint32_t t = 0; t < tiles; ++t) {
+                const uint32_t T = g * tiles + t, proto = T / tpp;
+                if (proto >= m.K) continue;
+                for (uint32_t j = 0; j < steps; ++j)
+                    for (uint32_t lane = 0; lane < 64; ++lane) {
+                        const uint32_t r = 32 * (T % tpp) + (lane & 31), d0 = chunk * c + 4 * (2 * j + (lane >> 5));
+                        float *dst = &img1[(((((size_t)g * NC + c) * tiles + t) * steps + j) * 64 + lane) * 4];
+                        for (uint32_t e = 0; e < 4; ++e)
+                            if (r < m.M && d0 + e < m.D) dst[e] = Oms[((size_t)proto * m.M + r) * m.D + d0 + e];
+                    }
+            }
+    img2.assign((size_t)groups * tiles * TAIL_FLOATS, 0.0f);
+    for (uint32_t T = 0; T < total; ++T)
+        for (uint32_t row = 0; row < 32; ++row) {
+            const uint32_t r = 32 * (T % tpp) + row;
+            if (r < m.M) img2[(size_t)T * TAIL_FLOATS + row] = negp[(size_t)(T / tpp) * m.M + r];
+        }
+    m.ngroups1 = groups;
+    m.tiles_per_proto = tpp;
+    m.launch = fn;
+    m.samples_per_batch = 32;
+    m.name = "mfma_local_long";
+    return true;
+}
+
 template <int R1>
 bool bind_local(EngineModel &m, std::vector<float> &img, const std::vector<float> &Oms, const std::vector<float> &negp,
                 const std::vector<uint32_t> &cls)
@@ -299,9 +339,10 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                           hipError_t &herr)
 {
     herr = hipSuccess;
-    if (D > 256 && !(((omega_kind == OMEGA_NONE && K <= 4096) || (omega_kind == OMEGA_GLOBAL && M <= 128)) && D <= 65536 &&
+    if (D > 256 && !(((omega_kind == OMEGA_NONE && K <= 4096) || (omega_kind == OMEGA_GLOBAL && M <= 128) ||
+                       (omega_kind == OMEGA_LOCAL && (uint64_t)K * ((M + 31) / 32) <= 2048)) && D <= 65536 &&
                      !getenv("VQHIP_NO_LONG"))) {
-        why = "sample length above 256 (served for Euclidean models with at most 4096 prototypes and for a global Omega of at most 128 rows)";
+        why = "sample length above 256 (served for Euclidean models with at most 4096 prototypes, a global Omega of at most 128 rows, local Omegas of at most 2048 tiles of 32 rows)";
         return nullptr;
     }
     if (omega_kind != OMEGA_NONE && M > 256) {
@@ -385,7 +426,7 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                     t += (double)Om[((size_t)j * M + r) * D + d] * (double)W[(size_t)j * D + d];
                 negp[(size_t)j * M + r] = (float)(-t);
             }
-        ok = bind_local<16>(m, img1, Om, negp, cls) || bind_local<32>(m, img1, Om, negp, cls) ||
+        ok = bind_local_long(m, img1, img2, Om, negp) || bind_local<16>(m, img1, Om, negp, cls) || bind_local<32>(m, img1, Om, negp, cls) ||
              bind_local<64>(m, img1, Om, negp, cls) || bind_local<128>(m, img1, Om, negp, cls) ||
              bind_local<256>(m, img1, Om, negp, cls);
     }

@@ -429,6 +429,154 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
     }
 }
 
+// ------------------------------------------------------------------------------ LGMLVQ with long rows
+// Local Omegas over rows above 256 values (src/lgmlvq/lgmlvq.rs:436-455, 468-506).  Every Omega_j is padded to
+// whole tiles of 32 rows and the tiles of all prototypes are stacked: pass 1 of k_long over groups of NT tiles with
+// the accumulators starting at -Omega_j w_j, so a finished tile holds 32 rows of z = Omega_j (x - w_j).  The
+// epilogue sums z^2 over the tile's rows and the tiles of a prototype and offers the total in index order
+// (strict '<', lgmlvq.rs:448); there is no screening and no second pass, the sum IS the direct form.
+template <int NT, bool MATCHED, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_local_long(const EngineArgs a)
+{
+    constexpr int NJ = 8, DEPTH = 8;
+    constexpr uint32_t CHUNK = NJ * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t NC = (a.D + CHUNK - 1) / CHUNK, NG = a.ngroups1, npieces = NG * NC * NT * NJ;
+    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, (int)(npieces * 1024u), 0x00020000);
+    const uint32_t om_off = (uint32_t)lane * 16u;
+    auto piece = [&](uint32_t p) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, (int)(p * 1024u), 0));
+    };
+    const float *tails = a.img2;                       // per tile: 32 x -(Omega_j w_j) of its rows (pad rows 0)
+
+    constexpr uint32_t BLOCK = 2;
+    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    queue.request();
+
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    f32x4 xa[NJ], xb[NJ];
+    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
+    };
+    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
+        if ((c + 1u) * CHUNK > a.D) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
+        }
+    };
+    uint32_t ln[BLOCK];
+#pragma unroll
+    for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
+    auto fetch_label = [&](uint32_t q, uint64_t bb) {
+        if (MATCHED) {
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+            ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+        }
+    };
+    fetch_x(xa, block0, 0);
+    fetch_label(0, block0);
+    fetch_label(1, block0 + 1);
+
+    while (block0 < a.nbatches) {
+        const uint64_t nb0 = queue.take();
+        queue.request();
+#pragma unroll
+        for (uint32_t q = 0; q < BLOCK; ++q) {
+            const uint64_t b = block0 + q;
+            const uint64_t bnext = q + 1 < BLOCK ? b + 1 : nb0;
+            const uint32_t label = ln[q];
+            f32x4 ring[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = piece((uint32_t)i);
+            uint32_t pnext = DEPTH;                    // the ring runs on across the groups
+            Best1 wp, wn;
+            float dsum = 0.0f;
+            uint32_t proto = 0, tin = 0;               // prototype of the current tile, its tile inside the prototype
+            for (uint32_t grp = 0; grp < NG; ++grp) {
+                const float *gtails = tails + (size_t)grp * NT * TAIL_FLOATS;
+                f32x16 acc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 ci = *(const f32x4 *)(gtails + t * TAIL_FLOATS + 8 * g + 4 * h);
+                        acc[t][4 * g + 0] = ci[0]; acc[t][4 * g + 1] = ci[1]; acc[t][4 * g + 2] = ci[2]; acc[t][4 * g + 3] = ci[3];
+                    }
+                auto mma = [&](const f32x4 (&xs)[NJ]) {
+                    static_for<0, NT>([&](auto tt) {
+                        static_for<0, NJ>([&](auto jj) {
+                            constexpr int j = decltype(jj)::value;
+                            const f32x4 av = ring[j % DEPTH];
+                            ring[j % DEPTH] = piece(pnext++);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[decltype(tt)::value] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xs[j][e], acc[decltype(tt)::value], 0, 0, 0);
+                        });
+                    });
+                };
+                for (uint32_t c = 0; c < NC; c += 2) {
+                    if (c + 1 < NC) fetch_x(xb, b, c + 1);
+                    cut(xa, c);
+                    mma(xa);
+                    if (c + 1 < NC) {
+                        if (c + 2 < NC) fetch_x(xa, b, c + 2);
+                        cut(xb, c + 1);
+                        mma(xb);
+                    }
+                }
+                asm volatile("" ::: "memory");
+                fetch_x(xa, grp + 1 < NG ? b : bnext, 0);     // the next group walks the rows again; after the last, the next batch
+                // ---- ||z||^2 per prototype, offered in index order
+                static_for<0, NT>([&](auto tt) {
+                    constexpr int t = decltype(tt)::value;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dsum = fmaf(acc[t][r], acc[t][r], dsum);
+                    if (++tin == a.tiles_per_proto) {
+                        const float total = dsum + xor32(dsum);
+                        dsum = 0.0f;
+                        if (proto < a.K) {                         // pad tiles past the last prototype never compete
+                            if (!MATCHED || a.cls[proto] == label) wp.offer(total, proto);     // lgmlvq.rs:448 / :487
+                            else wn.offer(total, proto);                                        // lgmlvq.rs:496
+                        }
+                        tin = 0;
+                        ++proto;
+                    }
+                });
+            }
+            {
+                const int rec = (int)records(b, 4u);
+                const uint32_t so = (uint32_t)s_col * 4u;
+                auto put = [&](void *base, uint32_t bits) {
+                    __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
+                };
+                if (h == 0) {
+                    if (a.out.idx) put(a.out.idx + b * 32, wp.i);
+                    if (MATCHED && a.out.jneg) put(a.out.jneg + b * 32, wn.i);
+                } else {
+                    if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
+                    if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
+                }
+            }
+            fetch_label(q, nb0 + q);
+        }
+        block0 = nb0;
+    }
+}
+
 namespace {
 template <int NT>
 hipError_t launch_long(const EngineArgs &a, bool matched, hipStream_t st)
@@ -467,6 +615,32 @@ LaunchFn omega_long_launcher(int R2)
     case 32: return &launch_omega_long<32>;
     case 64: return &launch_omega_long<64>;
     case 128: return &launch_omega_long<128>;
+    default: return nullptr;
+    }
+}
+
+namespace {
+template <int NT>
+hipError_t launch_local_long(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_local_long<NT, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_local_long<NT, false>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn local_long_launcher(int tiles)
+{
+    switch (tiles) {
+    case 1: return &launch_local_long<1>;
+    case 2: return &launch_local_long<2>;
+    case 4: return &launch_local_long<4>;
     default: return nullptr;
     }
 }

@@ -24,6 +24,7 @@ LaunchFn resident_staged_launcher(int R, size_t *staging_bytes);
 LaunchFn omega_pipe_launcher(int R);                                             // kernels_omega.hip: k_omega_pipe
 LaunchFn lowrank_launcher(int R1);                                               // kernels_omega.hip: k_lowrank_pipe
 LaunchFn long_launcher(int tiles);                                               // kernels_long.hip: k_long (rows above 256 values)
+LaunchFn local_long_launcher(int tiles);    // k_local_long<tiles>: LGMLVQ over rows above 256 values
 LaunchFn omega_long_launcher(int R2);                                            // kernels_long.hip: k_omega_long
 
 // batch counters of one launch (BlockQueue, mfma_device.h): QUEUE_GROUPS counters, 4 KiB apart
