@@ -129,8 +129,8 @@ int vqhip_assign_matched_device(vqhip_ctx *ctx, const float *dX, const uint32_t 
  *                                               LGMLVQ::project    src/lgmlvq/lgmlvq.rs:372-393
  * A global Omega with D <= 256 runs on the matrix cores (k_project: Omega / Lambda resident in LDS; Lambda is
  * built once in f64 as the reference builds it once, gmlvq.rs:357-358); LGMLVQ with D <= 256 groups the samples
- * by winner on the device and runs every group against its Lambda_j (k_project_local); D > 256 runs on the
- * scalar kernels. */
+ * by winner on the device and runs every group against its Lambda_j (k_project_local); a global Omega of at most
+ * 128 rows over D > 256 runs as Omega^T (Omega x) on the matrix cores (k_project_long); the rest on the scalar kernels. */
 typedef enum { VQHIP_PROJECT_OMEGA = 0, VQHIP_PROJECT_LAMBDA = 1 } vqhip_projection;
 int vqhip_project(vqhip_ctx *ctx, const float *X, uint64_t N, int which /* vqhip_projection */, float *Y);
 int vqhip_project_device(vqhip_ctx *ctx, const float *dX, uint64_t N, int which, float *dY, void *stream);

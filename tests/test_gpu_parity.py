@@ -478,6 +478,31 @@ def test_project_mfma_kernel(ctx, case):
         assert _rel_err(Y[:N].cpu().numpy(), want) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(500, 784, 16), (300, 300, 40), (200, 512, 128), (65, 1001, 3), (1000, 257, 100), (33, 2049, 64)],
+                         ids=lambda c: "n%d_d%d_m%d" % c)
+def test_project_long_rows(ctx, case):
+    """k_project_long: project / project_omega for a global Omega of at most 128 rows over rows above 256 values
+    (gmlvq.rs:354-372, liramlvq.rs:401-446): Omega x over chunks of 64 values, then Omega^T y out of the accumulators;
+    row lengths and output widths that are not multiples of 4 or 32, nothing written past N."""
+    import torch
+    from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
+    N, D, M = case
+    rng = np.random.default_rng(N + D + M)
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 2, D)).astype(np.float32)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(rng.uniform(-1, 1, size=(3, D)).astype(np.float32))
+    ctx.set_omega(Om)
+    Xd = torch.from_numpy(X).cuda()
+    for which, width, want in ((PROJECT_LAMBDA, D, oracle.project_lambda(Om, X[:N])), (PROJECT_OMEGA, M, oracle.project_omega(Om, X[:N]))):
+        Y = torch.full((N + 2, width), -7.0, dtype=torch.float32, device="cuda")
+        ctx.project_into(Xd[:N], Y[:N], which)
+        torch.cuda.synchronize()
+        assert ctx.last_kernel == "mfma_project_long"
+        assert (Y[N:].cpu().numpy() == -7.0).all()
+        assert _rel_err(Y[:N].cpu().numpy(), want) < 1e-5
+
+
 @pytest.mark.parametrize("shape", [s for s in SHAPES if s[6] == "local"], ids=lambda s: s[0])
 def test_project_local(ctx, shape):
     from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA

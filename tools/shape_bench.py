@@ -26,3 +26,14 @@ for _ in range(3): ctx.assign_into(X, idx, dist)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print(f"D={D} K={K} M={M} kernel={ctx.last_kernel} N={N} ms={ms:.3f} samples/s={N/ms*1e3:.4g} GB/s={N*(D*4+8)/ms/1e6:.0f}")
+if M and os.environ.get("SHAPE_BENCH_PROJECT"):
+    from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
+    for which, width, nm in ((PROJECT_LAMBDA, D, "project"), (PROJECT_OMEGA, M, "project_omega")):
+        Y = torch.empty((N, width), dtype=torch.float32, device="cuda")
+        for _ in range(2): ctx.project_into(X, Y, which)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3): ctx.project_into(X, Y, which)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        print(f"D={D} M={M} {nm} kernel={ctx.last_kernel} N={N} ms={ms:.3f} samples/s={N/ms*1e3:.4g} GB/s={N*(D+width)*4/ms/1e6:.0f}")

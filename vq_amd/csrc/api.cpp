@@ -54,6 +54,7 @@ struct vqhip_ctx {
     std::string engine_why;
     ProjectModel *proj_omega = nullptr, *proj_lambda = nullptr;   // matrix-core projections (global Omega)
     LocalProjectModel *proj_local = nullptr;                      // LGMLVQ::project (local Omegas)
+    LongProjectModel *proj_long = nullptr;                        // global Omega over rows above 256 values
     bool proj_tried = false;
 
     Staging st[2];
@@ -89,6 +90,8 @@ void drop_engine(vqhip_ctx *c)
     project_free(c->proj_omega);
     project_free(c->proj_lambda);
     local_project_free(c->proj_local);
+    long_project_free(c->proj_long);
+    c->proj_long = nullptr;
     c->proj_omega = c->proj_lambda = nullptr;
     c->proj_local = nullptr;
     c->proj_tried = false;
@@ -327,6 +330,11 @@ int prepare_project(vqhip_ctx *c)
         if (herr != hipSuccess) return c->fail_hip(herr, "local_project_build");
         return VQHIP_OK;
     }
+    if (c->D > 256) {
+        c->proj_long = long_project_build(c->hOm, c->M, c->D, herr);
+        if (herr != hipSuccess) return c->fail_hip(herr, "long_project_build");
+        return VQHIP_OK;
+    }
     c->proj_omega = project_build(c->hOm, c->M, c->D, herr);
     if (herr != hipSuccess) return c->fail_hip(herr, "project_build");
     if (!c->proj_omega) return VQHIP_OK;
@@ -355,6 +363,11 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
         if (pm && ((uintptr_t)dY & 3) == 0 && ((uintptr_t)dX & 3) == 0) {
             c->last_kernel = "mfma_project";
             HIPCHK(c, project_run(pm, dX, N, dY, ldy, s));
+            return VQHIP_OK;
+        }
+        if (c->proj_long && ((uintptr_t)dY & 3) == 0 && ((uintptr_t)dX & 3) == 0) {
+            c->last_kernel = "mfma_project_long";
+            HIPCHK(c, long_project_run(c->proj_long, dX, N, which == VQHIP_PROJECT_LAMBDA, dY, s));
             return VQHIP_OK;
         }
     }

@@ -9,6 +9,7 @@
 //           rooted, compared like helpers.rs:70.  The second fetch is the price of rows that fit neither the
 //           register file nor LDS; the kernel is HBM-bound at about twice the algorithmic bytes.
 #include <cstdlib>
+#include <vector>
 
 #include "mfma_device.h"
 
@@ -643,6 +644,257 @@ LaunchFn local_long_launcher(int tiles)
     case 4: return &launch_local_long<4>;
     default: return nullptr;
     }
+}
+
+// ------------------------------------------------------------------------------ project / project_omega over long rows
+// A global Omega of at most 128 rows over rows above 256 values (src/gmlvq/gmlvq.rs:354-372,
+// src/liramlvq/liramlvq.rs:401-446).  Stage 1 is the projection of k_omega_long: y = Omega x over chunks of 64
+// values, Omega's A fragments from L2.  project_omega stores y.  project goes on to Lambda x = Omega^T y with y as
+// the B fragment straight out of the accumulators: one output tile of 32 columns per pass over y, the A fragments
+// of Omega^T (pieces2) through a second ring, 16-byte stores as in k_project.
+struct LongProjectArgs {
+    const float *X;
+    uint64_t N;
+    uint32_t D, M;
+    const float *pieces1;     // Omega: NC x NT x 8 pieces
+    const float *pieces2;     // Omega^T: ceil(D / 32) x (R2 / 8) pieces
+    float *Y;                 // N x ldy
+    uint32_t ldy;
+    uint64_t nbatches;
+    uint32_t *queue;
+};
+
+template <int R2, bool LAMBDA, int NW = 8>
+__global__ void __launch_bounds__(NW * 64, NW / 4) k_project_long(const LongProjectArgs a)
+{
+    constexpr int NT = R2 / 32, NJ = 8, DEPTH = 8;
+    constexpr int NJ2 = R2 / 8, DEPTH2 = NJ2 < 8 ? NJ2 : 8;
+    constexpr uint32_t CHUNK = NJ * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t NC = (a.D + CHUNK - 1) / CHUNK, npieces = NC * NT * NJ, DT = (a.D + 31) / 32;
+    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.pieces1, 0, (int)(npieces * 1024u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rot =
+        __builtin_amdgcn_make_buffer_rsrc((void *)a.pieces2, 0, LAMBDA ? (int)(DT * NJ2 * 1024u) : 0, 0x00020000);
+    const uint32_t om_off = (uint32_t)lane * 16u;
+    auto piece = [&](uint32_t p) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, (int)(p * 1024u), 0));
+    };
+    auto piece2 = [&](uint32_t p) {                    // past the last piece: range-check zeros, never used
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rot, om_off, (int)(p * 1024u), 0));
+    };
+
+    constexpr uint32_t BLOCK = 2;
+    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
+    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    queue.request();
+
+    const uint32_t row_bytes = a.D * 4u, ybytes = a.ldy * 4u, out_dim = LAMBDA ? a.D : a.M;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    const uint32_t yoff = (uint32_t)s_col * ybytes;
+    const bool vec_store = (a.ldy & 3u) == 0u && ((uintptr_t)a.Y & 15u) == 0u;
+    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
+        const uint64_t first = bb * 32;
+        if (first >= a.N) return 0u;
+        const uint64_t left = (a.N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    };
+    f32x4 xa[NJ], xb[NJ];
+    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
+    };
+    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
+        if ((c + 1u) * CHUNK > a.D) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
+        }
+    };
+    fetch_x(xa, block0, 0);
+
+    while (block0 < a.nbatches) {
+        const uint64_t nb0 = queue.take();
+        queue.request();
+#pragma unroll
+        for (uint32_t q = 0; q < BLOCK; ++q) {
+            const uint64_t b = block0 + q;
+            const uint64_t bnext = q + 1 < BLOCK ? b + 1 : nb0;
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            f32x4 ring[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) ring[i] = piece((uint32_t)i);
+            uint32_t pnext = DEPTH;
+            auto mma = [&](const f32x4 (&xs)[NJ]) {
+                static_for<0, NT>([&](auto tt) {
+                    static_for<0, NJ>([&](auto jj) {
+                        constexpr int j = decltype(jj)::value;
+                        const f32x4 av = ring[j % DEPTH];
+                        ring[j % DEPTH] = piece(pnext++);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[decltype(tt)::value] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], xs[j][e], acc[decltype(tt)::value], 0, 0, 0);
+                    });
+                });
+            };
+            for (uint32_t c = 0; c < NC; c += 2) {
+                if (c + 1 < NC) fetch_x(xb, b, c + 1);
+                cut(xa, c);
+                mma(xa);
+                if (c + 1 < NC) {
+                    if (c + 2 < NC) fetch_x(xa, b, c + 2);
+                    cut(xb, c + 1);
+                    mma(xb);
+                }
+            }
+            asm volatile("" ::: "memory");
+            fetch_x(xa, bnext, 0);                     // x is dead: the next batch's first chunk
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.Y + b * 32 * a.ldy), 0, (int)records(b, ybytes), 0x00020000);
+            // accumulator group g of output tile T = columns 32 T + 8 g + 4 h .. + 3 of this lane's sample
+            auto store_tile = [&](const f32x16 &v, uint32_t T) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t col = 32u * T + 8u * g + 4u * h;
+                    if (vec_store && col + 4u <= out_dim) {
+                        const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, yoff + col * 4u, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float val = v[4 * g + e];
+                            if (col + e < out_dim)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ry, yoff + (col + e) * 4u, 0, 0);
+                        }
+                    }
+                }
+            };
+            if constexpr (!LAMBDA) {
+                static_for<0, NT>([&](auto tt) { store_tile(acc[decltype(tt)::value], (uint32_t)decltype(tt)::value); });
+            } else {
+                f32x4 yf[NJ2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) yf[4 * t + g] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                f32x4 ring2[DEPTH2];
+#pragma unroll
+                for (int i = 0; i < DEPTH2; ++i) ring2[i] = piece2((uint32_t)i);
+                uint32_t p2 = DEPTH2;
+                for (uint32_t T = 0; T < DT; ++T) {
+                    f32x16 o;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+                    static_for<0, NJ2>([&](auto jj) {
+                        constexpr int j = decltype(jj)::value;
+                        const f32x4 av = ring2[j % DEPTH2];
+                        ring2[j % DEPTH2] = piece2(p2++);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], yf[j][e], o, 0, 0, 0);
+                    });
+                    store_tile(o, T);
+                }
+            }
+        }
+        block0 = nb0;
+    }
+}
+
+struct LongProjectModel {
+    uint32_t D = 0, M = 0, R2 = 0;
+    float *pieces1 = nullptr, *pieces2 = nullptr;
+    uint32_t *queue = nullptr;
+    mutable uint32_t next_slot = 0;
+    void (*launch)(const LongProjectArgs &, bool lambda, unsigned grid, hipStream_t) = nullptr;
+};
+
+namespace {
+template <int R2>
+void launch_project_long(const LongProjectArgs &a, bool lambda, unsigned grid, hipStream_t st)
+{
+    if (lambda)
+        hipLaunchKernelGGL((k_project_long<R2, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_project_long<R2, false>), dim3(grid), dim3(512), 0, st, a);
+}
+}  // namespace
+
+LongProjectModel *long_project_build(const std::vector<float> &Om, uint32_t M, uint32_t D, hipError_t &herr)
+{
+    herr = hipSuccess;
+    if (D <= 256 || D > 65536 || M == 0 || M > 128) return nullptr;
+    LongProjectModel m;
+    m.D = D;
+    m.M = M;
+    m.R2 = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
+    m.launch = m.R2 == 32 ? &launch_project_long<32> : (m.R2 == 64 ? &launch_project_long<64> : &launch_project_long<128>);
+    const uint32_t NT = m.R2 / 32, steps = 8, chunk = 64, NC = (D + chunk - 1) / chunk, DT = (D + 31) / 32, NJ2 = m.R2 / 8;
+    // Omega: piece (c, t, j), lane (row, h) = Omega[32 t + row][64 c + 4 (2 j + h) .. + 3]
+    std::vector<float> p1((size_t)NC * NT * steps * 256, 0.0f), p2((size_t)DT * NJ2 * 256, 0.0f);
+    for (uint32_t c = 0; c < NC; ++c)
+        for (uint32_t t = 0; t < NT; ++t)
+            for (uint32_t j = 0; j < steps; ++j)
+                for (uint32_t lane = 0; lane < 64; ++lane) {
+                    const uint32_t r = 32 * t + (lane & 31), d0 = chunk * c + 4 * (2 * j + (lane >> 5));
+                    float *dst = &p1[((((size_t)c * NT + t) * steps + j) * 64 + lane) * 4];
+                    for (uint32_t e = 0; e < 4; ++e)
+                        if (r < M && d0 + e < D) dst[e] = Om[(size_t)r * D + d0 + e];
+                }
+    // Omega^T: piece (T, j), lane (row, h) = Omega^T[32 T + row][4 (2 j + h) .. + 3] = Omega[4 (2 j + h) + e][32 T + row]
+    for (uint32_t T = 0; T < DT; ++T)
+        for (uint32_t j = 0; j < NJ2; ++j)
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t d = 32 * T + (lane & 31), r0 = 4 * (2 * j + (lane >> 5));
+                float *dst = &p2[(((size_t)T * NJ2 + j) * 64 + lane) * 4];
+                for (uint32_t e = 0; e < 4; ++e)
+                    if (d < D && r0 + e < M) dst[e] = Om[(size_t)(r0 + e) * D + d];
+            }
+    LongProjectModel *out = new LongProjectModel(m);
+    auto up = [&](float **dst, const std::vector<float> &v) {
+        hipError_t e = hipMalloc((void **)dst, v.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+        return e;
+    };
+    herr = up(&out->pieces1, p1);
+    if (herr == hipSuccess) herr = up(&out->pieces2, p2);
+    if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, 16 * QUEUE_BYTES);
+    if (herr != hipSuccess) {
+        long_project_free(out);
+        return nullptr;
+    }
+    return out;
+}
+
+void long_project_free(LongProjectModel *m)
+{
+    if (!m) return;
+    (void)hipFree(m->pieces1);
+    (void)hipFree(m->pieces2);
+    (void)hipFree(m->queue);
+    delete m;
+}
+
+// dY: N x ldy with ldy = M (project_omega) or D (project)
+hipError_t long_project_run(const LongProjectModel *m, const float *dX, uint64_t N, bool lambda, float *dY, hipStream_t s)
+{
+    if (N == 0) return hipSuccess;
+    LongProjectArgs a;
+    a.X = dX; a.N = N; a.D = m->D; a.M = m->M;
+    a.pieces1 = m->pieces1; a.pieces2 = m->pieces2;
+    a.Y = dY; a.ldy = lambda ? m->D : m->M;
+    a.nbatches = (N + 31) / 32;
+    a.queue = m->queue + (size_t)(m->next_slot++ % 16) * (QUEUE_BYTES / sizeof(uint32_t));
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, s);
+    if (e != hipSuccess) return e;
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    m->launch(a, lambda, (unsigned)(wgs < 256 ? wgs : 256), s);
+    return hipGetLastError();
 }
 
 LaunchFn long_launcher(int tiles)

@@ -80,6 +80,12 @@ ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t
 void project_free(ProjectModel *m);
 hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float *dY, uint32_t ldy, hipStream_t s);
 
+// project / project_omega for a global Omega of at most 128 rows over rows above 256 values (kernels_long.hip)
+struct LongProjectModel;
+LongProjectModel *long_project_build(const std::vector<float> &Om, uint32_t M, uint32_t D, hipError_t &herr);
+void long_project_free(LongProjectModel *m);
+hipError_t long_project_run(const LongProjectModel *m, const float *dX, uint64_t N, bool lambda, float *dY, hipStream_t s);
+
 // LGMLVQ::project on the matrix cores (kernels_project.hip): samples grouped by winner, Lambda_j from L2
 struct LocalProjectModel;
 LocalProjectModel *local_project_build(const std::vector<float> &Oms, uint32_t K, uint32_t M, uint32_t D, hipError_t &herr);
