@@ -15,6 +15,52 @@
 
 namespace vq {
 
+// The rows of a batch of 32 samples, walked in chunks of NJ * 8 values: lane (s, h) holds the 16-byte pieces 2 j + h
+// of its sample's chunk.  Rows past N and bytes past the last row read as zeros (buffer range check); values at or
+// past D inside the last chunk -- they belong to the next row -- are cleared by cut().
+template <int NJ>
+struct RowWalker {
+    static constexpr uint32_t CHUNK = NJ * 8;
+    const float *X;
+    uint64_t N;
+    uint32_t D, row_bytes, voff;
+    int h;
+    __device__ __forceinline__ RowWalker(const float *X_, uint64_t N_, uint32_t D_, int s_col, int h_)
+        : X(X_), N(N_), D(D_), row_bytes(D_ * 4u), voff((uint32_t)s_col * D_ * 4u + (uint32_t)h_ * 16u), h(h_)
+    {
+    }
+    // num_records of a descriptor that starts at batch bb of an array with `unit` bytes per sample
+    __device__ __forceinline__ uint32_t records(uint64_t bb, uint32_t unit) const
+    {
+        const uint64_t first = bb * 32;
+        if (first >= N) return 0u;
+        const uint64_t left = (N - first) * unit;
+        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
+    }
+    // chunk c of batch bb
+    __device__ __forceinline__ void fetch(f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) const
+    {
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void *)(X + bb * 32 * D), 0, (int)records(bb, row_bytes), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
+    }
+    __device__ __forceinline__ void cut(f32x4 (&xs)[NJ], uint32_t c) const
+    {
+        if ((c + 1u) * CHUNK > D) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), D);
+        }
+    }
+    // class id of this lane's sample in batch bb
+    __device__ __forceinline__ uint32_t label(const uint32_t *y, uint64_t bb, int s_col) const
+    {
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+    }
+};
+
 template <int NT, bool MATCHED, int NW = 8>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
 {
@@ -40,39 +86,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     queue.request();
 
-    const uint32_t row_bytes = a.D * 4u;
-    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
-    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
-        const uint64_t first = bb * 32;
-        if (first >= a.N) return 0u;
-        const uint64_t left = (a.N - first) * unit;
-        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
-    };
+    const RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
     f32x4 xa[NJ], xb[NJ];                              // two chunks of the rows, worked alternately
-    // chunk c of batch bb: lane (s, h) gets the 16-byte pieces 2j + h of values [128 c, 128 c + 128) of row s
-    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
-        const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
-    };
-    // values at or past D (the last chunk's tail: the next row, or range-check zeros) are cleared
-    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
-        if ((c + 1u) * CHUNK > a.D) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
-        }
-    };
     // fn(chunk registers, chunk number) over all chunks of batch bb; xa must hold (or be receiving) chunk 0
     auto for_chunks = [&](uint64_t bb, auto &&fn) {
         for (uint32_t c = 0; c < NC; c += 2) {
-            if (c + 1 < NC) fetch_x(xb, bb, c + 1);
-            cut(xa, c);
+            if (c + 1 < NC) rows.fetch(xb, bb, c + 1);
+            rows.cut(xa, c);
             fn(xa, c);
             if (c + 1 < NC) {
-                if (c + 2 < NC) fetch_x(xa, bb, c + 2);
-                cut(xb, c + 1);
+                if (c + 2 < NC) rows.fetch(xa, bb, c + 2);
+                rows.cut(xb, c + 1);
                 fn(xb, c + 1);
             }
         }
@@ -81,7 +105,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
     auto exact_pair = [&](uint64_t bb, uint32_t k0, uint32_t k1, float &e0, float &e1) {
         const float *w0 = a.plain + (size_t)k0 * a.ldp + 4 * h, *w1 = a.plain + (size_t)k1 * a.ldp + 4 * h;
         float p0 = 0.0f, p1 = 0.0f;
-        fetch_x(xa, bb, 0);
+        rows.fetch(xa, bb, 0);
         for_chunks(bb, [&](const f32x4 (&xs)[NJ], uint32_t c) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -102,13 +126,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
 #pragma unroll
     for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
     auto fetch_label = [&](uint32_t q, uint64_t bb) {
-        if (MATCHED) {
-            const __amdgpu_buffer_rsrc_t ry =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
-            ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
-        }
+        if (MATCHED) ln[q] = rows.label(a.y, bb, s_col);
     };
-    fetch_x(xa, block0, 0);
+    rows.fetch(xa, block0, 0);
     fetch_label(0, block0);
     fetch_label(1, block0 + 1);
 
@@ -157,7 +177,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                     });
                 });
             });
-            if (grp + 1 < NG) fetch_x(xa, b, 0);       // the next group walks the rows again
+            if (grp + 1 < NG) rows.fetch(xa, b, 0);       // the next group walks the rows again
 
             // ---- screening
             static_for<0, NT>([&](auto tt) {
@@ -249,7 +269,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
             }
             settle_ties<MATCHED>(a, label, wp, wn);
             {
-                const int rec = (int)records(b, 4u);
+                const int rec = (int)rows.records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;
                 auto put = [&](void *base, uint32_t bits) {
                     __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
@@ -262,7 +282,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                     if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
                 }
             }
-            fetch_x(xa, bnext, 0);                     // the next batch's first chunk
+            rows.fetch(xa, bnext, 0);                     // the next batch's first chunk
             fetch_label(q, nb0 + q);
         }
         block0 = nb0;
@@ -310,39 +330,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     queue.request();
 
-    const uint32_t row_bytes = a.D * 4u;
-    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
-    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
-        const uint64_t first = bb * 32;
-        if (first >= a.N) return 0u;
-        const uint64_t left = (a.N - first) * unit;
-        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
-    };
+    const RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
     f32x4 xa[NJ], xb[NJ];
-    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
-        const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
-    };
-    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
-        if ((c + 1u) * CHUNK > a.D) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
-        }
-    };
     uint32_t ln[BLOCK];
 #pragma unroll
     for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
     auto fetch_label = [&](uint32_t q, uint64_t bb) {
-        if (MATCHED) {
-            const __amdgpu_buffer_rsrc_t ry =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
-            ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
-        }
+        if (MATCHED) ln[q] = rows.label(a.y, bb, s_col);
     };
-    fetch_x(xa, block0, 0);
+    rows.fetch(xa, block0, 0);
     fetch_label(0, block0);
     fetch_label(1, block0 + 1);
 
@@ -378,12 +374,12 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
                 });
             };
             for (uint32_t c = 0; c < NC; c += 2) {
-                if (c + 1 < NC) fetch_x(xb, b, c + 1);
-                cut(xa, c);
+                if (c + 1 < NC) rows.fetch(xb, b, c + 1);
+                rows.cut(xa, c);
                 mma(xa);
                 if (c + 1 < NC) {
-                    if (c + 2 < NC) fetch_x(xa, b, c + 2);
-                    cut(xb, c + 1);
+                    if (c + 2 < NC) rows.fetch(xa, b, c + 2);
+                    rows.cut(xb, c + 1);
                     mma(xb);
                 }
             }
@@ -393,7 +389,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
 #pragma unroll
                 for (int g = 0; g < 4; ++g) yf[4 * t + g] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
             asm volatile("" ::: "memory");
-            fetch_x(xa, bnext, 0);                     // x is dead: the next batch's first chunk lands during the search
+            rows.fetch(xa, bnext, 0);                     // x is dead: the next batch's first chunk lands during the search
             fetch_label(q, nb0 + q);
 
             float ss = 0.0f;
@@ -412,7 +408,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
             finish_keys<R2, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
             settle_ties<MATCHED>(a, label, wp, wn);
             {
-                const int rec = (int)records(b, 4u);
+                const int rec = (int)rows.records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;
                 auto put = [&](void *base, uint32_t bits) {
                     __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
@@ -456,39 +452,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_local_long(const EngineArgs
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     queue.request();
 
-    const uint32_t row_bytes = a.D * 4u;
-    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
-    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
-        const uint64_t first = bb * 32;
-        if (first >= a.N) return 0u;
-        const uint64_t left = (a.N - first) * unit;
-        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
-    };
+    const RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
     f32x4 xa[NJ], xb[NJ];
-    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
-        const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
-    };
-    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
-        if ((c + 1u) * CHUNK > a.D) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
-        }
-    };
     uint32_t ln[BLOCK];
 #pragma unroll
     for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
     auto fetch_label = [&](uint32_t q, uint64_t bb) {
-        if (MATCHED) {
-            const __amdgpu_buffer_rsrc_t ry =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + bb * 32), 0, (int)records(bb, 4u), 0x00020000);
-            ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
-        }
+        if (MATCHED) ln[q] = rows.label(a.y, bb, s_col);
     };
-    fetch_x(xa, block0, 0);
+    rows.fetch(xa, block0, 0);
     fetch_label(0, block0);
     fetch_label(1, block0 + 1);
 
@@ -530,17 +502,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_local_long(const EngineArgs
                     });
                 };
                 for (uint32_t c = 0; c < NC; c += 2) {
-                    if (c + 1 < NC) fetch_x(xb, b, c + 1);
-                    cut(xa, c);
+                    if (c + 1 < NC) rows.fetch(xb, b, c + 1);
+                    rows.cut(xa, c);
                     mma(xa);
                     if (c + 1 < NC) {
-                        if (c + 2 < NC) fetch_x(xa, b, c + 2);
-                        cut(xb, c + 1);
+                        if (c + 2 < NC) rows.fetch(xa, b, c + 2);
+                        rows.cut(xb, c + 1);
                         mma(xb);
                     }
                 }
                 asm volatile("" ::: "memory");
-                fetch_x(xa, grp + 1 < NG ? b : bnext, 0);     // the next group walks the rows again; after the last, the next batch
+                rows.fetch(xa, grp + 1 < NG ? b : bnext, 0);     // the next group walks the rows again; after the last, the next batch
                 // ---- ||z||^2 per prototype, offered in index order
                 static_for<0, NT>([&](auto tt) {
                     constexpr int t = decltype(tt)::value;
@@ -559,7 +531,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_local_long(const EngineArgs
                 });
             }
             {
-                const int rec = (int)records(b, 4u);
+                const int rec = (int)rows.records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;
                 auto put = [&](void *base, uint32_t bits) {
                     __builtin_amdgcn_raw_buffer_store_b32(bits, __builtin_amdgcn_make_buffer_rsrc(base, 0, rec, 0x00020000), so, 0, 0);
@@ -689,31 +661,12 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project_long(const LongProj
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     queue.request();
 
-    const uint32_t row_bytes = a.D * 4u, ybytes = a.ldy * 4u, out_dim = LAMBDA ? a.D : a.M;
-    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    const uint32_t ybytes = a.ldy * 4u, out_dim = LAMBDA ? a.D : a.M;
+    const RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
     const uint32_t yoff = (uint32_t)s_col * ybytes;
     const bool vec_store = (a.ldy & 3u) == 0u && ((uintptr_t)a.Y & 15u) == 0u;
-    auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
-        const uint64_t first = bb * 32;
-        if (first >= a.N) return 0u;
-        const uint64_t left = (a.N - first) * unit;
-        return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
-    };
     f32x4 xa[NJ], xb[NJ];
-    auto fetch_x = [&](f32x4 (&xs)[NJ], uint64_t bb, uint32_t c) {
-        const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            xs[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, (int)(c * CHUNK * 4u), 0));
-    };
-    auto cut = [&](f32x4 (&xs)[NJ], uint32_t c) {
-        if ((c + 1u) * CHUNK > a.D) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) xs[j] = mask_chunk(xs[j], c * (CHUNK / 4) + (uint32_t)(2 * j + h), a.D);
-        }
-    };
-    fetch_x(xa, block0, 0);
+    rows.fetch(xa, block0, 0);
 
     while (block0 < a.nbatches) {
         const uint64_t nb0 = queue.take();
@@ -744,19 +697,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project_long(const LongProj
                 });
             };
             for (uint32_t c = 0; c < NC; c += 2) {
-                if (c + 1 < NC) fetch_x(xb, b, c + 1);
-                cut(xa, c);
+                if (c + 1 < NC) rows.fetch(xb, b, c + 1);
+                rows.cut(xa, c);
                 mma(xa);
                 if (c + 1 < NC) {
-                    if (c + 2 < NC) fetch_x(xa, b, c + 2);
-                    cut(xb, c + 1);
+                    if (c + 2 < NC) rows.fetch(xa, b, c + 2);
+                    rows.cut(xb, c + 1);
                     mma(xb);
                 }
             }
             asm volatile("" ::: "memory");
-            fetch_x(xa, bnext, 0);                     // x is dead: the next batch's first chunk
+            rows.fetch(xa, bnext, 0);                     // x is dead: the next batch's first chunk
             const __amdgpu_buffer_rsrc_t ry =
-                __builtin_amdgcn_make_buffer_rsrc((void *)(a.Y + b * 32 * a.ldy), 0, (int)records(b, ybytes), 0x00020000);
+                __builtin_amdgcn_make_buffer_rsrc((void *)(a.Y + b * 32 * a.ldy), 0, (int)rows.records(b, ybytes), 0x00020000);
             // accumulator group g of output tile T = columns 32 T + 8 g + 4 h .. + 3 of this lane's sample
             auto store_tile = [&](const f32x16 &v, uint32_t T) {
 #pragma unroll
