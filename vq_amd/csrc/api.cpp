@@ -351,6 +351,20 @@ int prepare_project(vqhip_ctx *c)
     return VQHIP_OK;
 }
 
+// The projection scratch holds at least `need` 4-byte words (grown after the stream has drained: kernels in
+// flight may still use the old buffer).
+int ensure_proj_scratch(vqhip_ctx *c, size_t need, hipStream_t s)
+{
+    if (c->dProj_cap >= need) return VQHIP_OK;
+    HIPCHK(c, hipStreamSynchronize(s));
+    (void)hipFree(c->dProj);
+    c->dProj = nullptr;
+    c->dProj_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&c->dProj, need * sizeof(float)));
+    c->dProj_cap = need;
+    return VQHIP_OK;
+}
+
 // One device-resident batch of project / project_omega, enqueued on `s`.
 int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *dY, hipStream_t s)
 {
@@ -377,14 +391,7 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
         const LocalProjectModel *pm = c->proj_local;
         const uint64_t chunk = std::min<uint64_t>(N, std::min<uint64_t>(local_project_max_rows(pm), 4ull << 20));
         const size_t need = (size_t)chunk + local_project_scratch_words(pm, chunk);
-        if (c->dProj_cap < need) {
-            HIPCHK(c, hipStreamSynchronize(s));
-            (void)hipFree(c->dProj);
-            c->dProj = nullptr;
-            c->dProj_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->dProj, need * sizeof(float)));
-            c->dProj_cap = need;
-        }
+        if ((rc = ensure_proj_scratch(c, need, s)) != VQHIP_OK) return rc;
         uint32_t *dwin = (uint32_t *)c->dProj;
         if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
         for (uint64_t off = 0; off < N; off += chunk) {
@@ -404,14 +411,7 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
     // Lambda x = Omega^T (Omega x): chunks of rows through an N x M intermediate (+ the winners, local case)
     const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (64ull << 20) / ((c->M + 1) * 4ull)));
     const size_t need = (size_t)chunk * (c->M + 1);
-    if (c->dProj_cap < need) {
-        HIPCHK(c, hipStreamSynchronize(s));
-        (void)hipFree(c->dProj);
-        c->dProj = nullptr;
-        c->dProj_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->dProj, need * sizeof(float)));
-        c->dProj_cap = need;
-    }
+    if ((rc = ensure_proj_scratch(c, need, s)) != VQHIP_OK) return rc;
     float *dT = c->dProj;
     uint32_t *dwin = (uint32_t *)(c->dProj + (size_t)chunk * c->M);
     if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
