@@ -845,6 +845,59 @@ def test_long_rows(ctx, case):
         assert rep.ok, f"{case} matching={matching}: {rep}"
 
 
+@pytest.mark.parametrize("case", [(300, 300, 20, 300), (200, 784, 10, 200), (150, 400, 300, 129), (100, 512, 5, 513), (65, 260, 3, 260)],
+                         ids=lambda c: "n%d_d%d_k%d_m%d" % c)
+def test_long_rows_tall_omega(ctx, case):
+    """A global Omega with more than 128 rows over rows above 256 values (GMLVQ's square Omega on long rows): two
+    passes -- k_project_long in blocks of 128 Omega rows into scratch, a Euclidean engine over W Omega^T in the
+    projected space, distances squared -- against the oracle, plain and matched, NaN / INF rows, project_omega."""
+    import torch
+    from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
+    N, D, K, M = case
+    rng = np.random.default_rng(N + D + K + M)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N + 2, D)).astype(np.float32)
+    X[5 % N, D - 1] = np.nan
+    X[40 % N, 0] = np.inf
+    o = oracle.assign(X[:N], W, omega=Om, threads=8)
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    ctx.set_prototypes(W)
+    ctx.set_omega(Om)
+    Xd = torch.from_numpy(X).cuda()
+    idx = torch.full((N + 2,), -7, dtype=torch.int32, device="cuda")
+    dist = torch.full((N + 2,), -7.0, dtype=torch.float32, device="cuda")
+    ctx.assign_into(Xd[:N], idx[:N], dist[:N])
+    torch.cuda.synchronize()
+    assert ctx.last_kernel == "mfma_omega_two_pass"
+    assert (idx[N:].cpu().numpy() == -7).all() and (dist[N:].cpu().numpy() == -7.0).all()
+    gi, gd = idx[:N].cpu().numpy(), dist[:N].cpu().numpy()
+    fin = np.isfinite(gd)
+    rep = parity.compare(gi[fin], gd[fin], o[0][fin], o[1][fin], o[2][fin], atol=2e-6)
+    assert rep.ok, str(rep)
+    assert not fin[5 % N] and gi[5 % N] == 0 and not fin[40 % N] and gi[40 % N] == 0
+    assert fin.sum() >= N - 2
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    ctx.set_labels(cls)
+    jp, dp, jn, dn = ctx.assign_matched(X[:N], y)
+    assert ctx.last_kernel == "mfma_omega_two_pass"
+    for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+        om = oracle.assign(X[:N], W, omega=Om, proto_cls=cls, labels=y, matching=matching, threads=8)
+        f2 = np.isfinite(d) | ~np.isfinite(om[1])
+        f2 &= fin | ~np.isfinite(om[1])
+        rep = parity.compare(j[f2], d[f2], om[0][f2], om[1][f2], om[2][f2], atol=2e-6)
+        assert rep.ok, f"{case} matching={matching}: {rep}"
+    Xc = X[:N].copy()
+    Xc[~np.isfinite(Xc)] = 0.5
+    Z = ctx.project(Xc, PROJECT_OMEGA)
+    assert ctx.last_kernel == "mfma_project_long"
+    assert _rel_err(Z, oracle.project_omega(Om, Xc)) < 1e-5
+    Y = ctx.project(Xc, PROJECT_LAMBDA)                                   # needs all of Omega x at once: scalar kernels
+    assert ctx.last_kernel == "scalar_project"
+    assert _rel_err(Y, oracle.project_lambda(Om, Xc)) < 1e-5
+
+
 @pytest.mark.parametrize("case", [(600, 784, 10, 10), (300, 300, 3, 40), (200, 512, 5, 33), (65, 1000, 1, 3), (500, 257, 37, 2), (150, 400, 2, 100)],
                          ids=lambda c: "n%d_d%d_k%d_m%d" % c)
 def test_long_rows_local(ctx, case):

@@ -50,6 +50,11 @@ struct vqhip_ctx {
     hipEvent_t scratch_done = nullptr;
 
     EngineModel *engine = nullptr;
+    // A global Omega the single-pass kernels do not hold (more than 128 rows over rows above 256 values): the samples
+    // are projected into scratch (k_project_long, blocks of 128 Omega rows) and searched there by a Euclidean
+    // engine over P = W Omega^T; the rooted distances are squared afterwards (helpers.rs:44).
+    EngineModel *engine2 = nullptr;
+    std::vector<float> hP;     // K x M: W . Omega^T (global Omega only)
     bool engine_tried = false;
     std::string engine_why;
     ProjectModel *proj_omega = nullptr, *proj_lambda = nullptr;   // matrix-core projections (global Omega)
@@ -84,7 +89,8 @@ namespace {
 void drop_engine(vqhip_ctx *c)
 {
     engine_free(c->engine);
-    c->engine = nullptr;
+    engine_free(c->engine2);
+    c->engine = c->engine2 = nullptr;
     c->engine_tried = false;
     c->engine_why.clear();
     project_free(c->proj_omega);
@@ -119,6 +125,7 @@ void free_omega(vqhip_ctx *c)
 {
     (void)hipFree(c->dOm); c->dOm = nullptr;
     (void)hipFree(c->dP);  c->dP = nullptr;
+    c->hP.clear();
     (void)hipFree(c->dOmT); c->dOmT = nullptr;
     c->hOm.clear();
     c->M = 0;
@@ -135,6 +142,8 @@ int upload(vqhip_ctx *c, T **dst, const T *src, size_t count)
     return VQHIP_OK;
 }
 
+int prepare_project(vqhip_ctx *c);
+
 // Makes sure the MFMA engine's tile images exist when the policy wants them.
 int prepare_engine(vqhip_ctx *c)
 {
@@ -145,7 +154,18 @@ int prepare_engine(vqhip_ctx *c)
         c->engine = engine_build(c->hW, c->K, c->D, c->hOm, c->omega_kind, c->M, c->hcls, c->engine_why, herr);
         if (herr != hipSuccess) return c->fail_hip(herr, "engine_build");
     }
-    if (!c->engine && c->policy == VQHIP_KERNEL_MFMA)
+    if (!c->engine && !c->engine2 && c->omega_kind == OMEGA_GLOBAL && c->D > 256 && c->M > 128) {
+        int rc = prepare_project(c);
+        if (rc != VQHIP_OK) return rc;
+        if (c->proj_long) {
+            hipError_t herr = hipSuccess;
+            std::string why2;
+            c->engine2 = engine_build(c->hP, c->K, c->M, std::vector<float>(), OMEGA_NONE, 0, c->hcls, why2, herr);
+            if (herr != hipSuccess) return c->fail_hip(herr, "engine_build (projected space)");
+            if (!c->engine2) c->engine_why += "; projected space: " + why2;
+        }
+    }
+    if (!c->engine && !c->engine2 && c->policy == VQHIP_KERNEL_MFMA)
         return c->fail(VQHIP_ERR_UNSUPPORTED, "MFMA engine not eligible for this model: " + c->engine_why);
     return VQHIP_OK;
 }
@@ -179,6 +199,33 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
         c->last_kernel = engine_name(c->engine);
         HIPCHK(c, engine_assign(c->engine, dX, N, dy, out, s));
         return VQHIP_OK;
+    }
+
+    if (c->engine2 && c->proj_long && c->policy != VQHIP_KERNEL_SCALAR && ((uintptr_t)dX & 3) == 0) {
+        const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (256ull << 20) / (c->M * 4ull)));
+        if (c->dYproj_cap < chunk * c->M) {
+            HIPCHK(c, hipStreamSynchronize(s));
+            (void)hipFree(c->dYproj);
+            c->dYproj = nullptr;
+            c->dYproj_cap = 0;
+            HIPCHK(c, hipMalloc((void **)&c->dYproj, chunk * c->M * sizeof(float)));
+            c->dYproj_cap = chunk * c->M;
+        }
+        if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
+        for (uint64_t off = 0; off < N; off += chunk) {
+            const uint64_t n = std::min(chunk, N - off);
+            Outputs o = out;
+            if (o.idx) o.idx += off;
+            if (o.dist) o.dist += off;
+            if (o.jneg) o.jneg += off;
+            if (o.dneg) o.dneg += off;
+            HIPCHK(c, long_project_run(c->proj_long, dX + off * c->D, n, false, c->dYproj, s));
+            HIPCHK(c, engine_assign(c->engine2, c->dYproj, n, dy ? dy + off : nullptr, o, s));
+            HIPCHK(c, launch_square(o.dist, n, s));
+            if (dy) HIPCHK(c, launch_square(o.dneg, n, s));
+        }
+        c->last_kernel = "mfma_omega_two_pass";
+        return scratch_release(c, s);
     }
 
     c->last_kernel = "scalar";
@@ -379,7 +426,8 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
             HIPCHK(c, project_run(pm, dX, N, dY, ldy, s));
             return VQHIP_OK;
         }
-        if (c->proj_long && ((uintptr_t)dY & 3) == 0 && ((uintptr_t)dX & 3) == 0) {
+        if (c->proj_long && (which == VQHIP_PROJECT_OMEGA || long_project_has_lambda(c->proj_long)) && ((uintptr_t)dY & 3) == 0 &&
+            ((uintptr_t)dX & 3) == 0) {
             c->last_kernel = "mfma_project_long";
             HIPCHK(c, long_project_run(c->proj_long, dX, N, which == VQHIP_PROJECT_LAMBDA, dY, s));
             return VQHIP_OK;
@@ -612,6 +660,7 @@ int vqhip_set_omega(vqhip_ctx *c, const float *Om, uint32_t M, uint32_t D)
         }
     rc = upload(c, &c->dP, P.data(), P.size());
     if (rc != VQHIP_OK) return rc;
+    c->hP = P;
     std::vector<float> OmT((size_t)D * M);
     for (uint32_t m = 0; m < M; ++m)
         for (uint32_t d = 0; d < D; ++d) OmT[(size_t)d * M + m] = Om[(size_t)m * D + d];

@@ -8,6 +8,7 @@
 //   pass 2  the rows are fetched again and the candidates re-measured in the direct sum (x_d - w_kd)^2 form,
 //           rooted, compared like helpers.rs:70.  The second fetch is the price of rows that fit neither the
 //           register file nor LDS; the kernel is HBM-bound at about twice the algorithmic bytes.
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -759,12 +760,14 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project_long(const LongProj
     }
 }
 
+// Omega rows are worked in blocks of at most 128 (the accumulators of one pass); project (Lambda) needs all of
+// Omega x in registers and is served for one block only.
 struct LongProjectModel {
-    uint32_t D = 0, M = 0, R2 = 0;
+    uint32_t D = 0, M = 0, nblocks = 0;
+    size_t block_floats = 0;                                      // pieces of one full block
     float *pieces1 = nullptr, *pieces2 = nullptr;
     uint32_t *queue = nullptr;
     mutable uint32_t next_slot = 0;
-    void (*launch)(const LongProjectArgs &, bool lambda, unsigned grid, hipStream_t) = nullptr;
 };
 
 namespace {
@@ -778,27 +781,36 @@ void launch_project_long(const LongProjectArgs &a, bool lambda, unsigned grid, h
 }
 }  // namespace
 
+namespace {
+uint32_t block_width(uint32_t rows) { return rows <= 32 ? 32 : (rows <= 64 ? 64 : 128); }
+}  // namespace
+
 LongProjectModel *long_project_build(const std::vector<float> &Om, uint32_t M, uint32_t D, hipError_t &herr)
 {
     herr = hipSuccess;
-    if (D <= 256 || D > 65536 || M == 0 || M > 128) return nullptr;
+    if (D <= 256 || D > 65536 || M == 0 || M > 4096) return nullptr;
     LongProjectModel m;
     m.D = D;
     m.M = M;
-    m.R2 = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
-    m.launch = m.R2 == 32 ? &launch_project_long<32> : (m.R2 == 64 ? &launch_project_long<64> : &launch_project_long<128>);
-    const uint32_t NT = m.R2 / 32, steps = 8, chunk = 64, NC = (D + chunk - 1) / chunk, DT = (D + 31) / 32, NJ2 = m.R2 / 8;
-    // Omega: piece (c, t, j), lane (row, h) = Omega[32 t + row][64 c + 4 (2 j + h) .. + 3]
-    std::vector<float> p1((size_t)NC * NT * steps * 256, 0.0f), p2((size_t)DT * NJ2 * 256, 0.0f);
-    for (uint32_t c = 0; c < NC; ++c)
-        for (uint32_t t = 0; t < NT; ++t)
-            for (uint32_t j = 0; j < steps; ++j)
-                for (uint32_t lane = 0; lane < 64; ++lane) {
-                    const uint32_t r = 32 * t + (lane & 31), d0 = chunk * c + 4 * (2 * j + (lane >> 5));
-                    float *dst = &p1[((((size_t)c * NT + t) * steps + j) * 64 + lane) * 4];
-                    for (uint32_t e = 0; e < 4; ++e)
-                        if (r < M && d0 + e < D) dst[e] = Om[(size_t)r * D + d0 + e];
-                }
+    m.nblocks = (M + 127) / 128;
+    const uint32_t steps = 8, chunk = 64, NC = (D + chunk - 1) / chunk, DT = (D + 31) / 32;
+    const uint32_t R2 = block_width(M), NJ2 = R2 / 8;                     // (pieces2: one block only)
+    m.block_floats = (size_t)NC * 4 * steps * 256;
+    // Omega, per block of 128 rows: piece (c, t, j), lane (row, h) = Omega[128 b + 32 t + row][64 c + 4 (2 j + h) .. + 3];
+    // the last block has NT = its own width / 32 tiles
+    std::vector<float> p1((size_t)m.nblocks * m.block_floats, 0.0f), p2((size_t)DT * NJ2 * 256, 0.0f);
+    for (uint32_t b = 0; b < m.nblocks; ++b) {
+        const uint32_t rows = std::min(128u, M - 128 * b), NT = block_width(rows) / 32;
+        for (uint32_t c = 0; c < NC; ++c)
+            for (uint32_t t = 0; t < NT; ++t)
+                for (uint32_t j = 0; j < steps; ++j)
+                    for (uint32_t lane = 0; lane < 64; ++lane) {
+                        const uint32_t r = 128 * b + 32 * t + (lane & 31), d0 = chunk * c + 4 * (2 * j + (lane >> 5));
+                        float *dst = &p1[b * m.block_floats + ((((size_t)c * NT + t) * steps + j) * 64 + lane) * 4];
+                        for (uint32_t e = 0; e < 4; ++e)
+                            if (r < M && d0 + e < D) dst[e] = Om[(size_t)r * D + d0 + e];
+                    }
+    }
     // Omega^T: piece (T, j), lane (row, h) = Omega^T[32 T + row][4 (2 j + h) .. + 3] = Omega[4 (2 j + h) + e][32 T + row]
     for (uint32_t T = 0; T < DT; ++T)
         for (uint32_t j = 0; j < NJ2; ++j)
@@ -806,7 +818,7 @@ LongProjectModel *long_project_build(const std::vector<float> &Om, uint32_t M, u
                 const uint32_t d = 32 * T + (lane & 31), r0 = 4 * (2 * j + (lane >> 5));
                 float *dst = &p2[(((size_t)T * NJ2 + j) * 64 + lane) * 4];
                 for (uint32_t e = 0; e < 4; ++e)
-                    if (d < D && r0 + e < M) dst[e] = Om[(size_t)(r0 + e) * D + d];
+                    if (m.nblocks == 1 && d < D && r0 + e < M) dst[e] = Om[(size_t)(r0 + e) * D + d];
             }
     LongProjectModel *out = new LongProjectModel(m);
     auto up = [&](float **dst, const std::vector<float> &v) {
@@ -833,20 +845,29 @@ void long_project_free(LongProjectModel *m)
     delete m;
 }
 
-// dY: N x ldy with ldy = M (project_omega) or D (project)
+bool long_project_has_lambda(const LongProjectModel *m) { return m->nblocks == 1; }
+
+// dY: N x ldy with ldy = M (project_omega) or D (project; one block of Omega rows only)
 hipError_t long_project_run(const LongProjectModel *m, const float *dX, uint64_t N, bool lambda, float *dY, hipStream_t s)
 {
     if (N == 0) return hipSuccess;
-    LongProjectArgs a;
-    a.X = dX; a.N = N; a.D = m->D; a.M = m->M;
-    a.pieces1 = m->pieces1; a.pieces2 = m->pieces2;
-    a.Y = dY; a.ldy = lambda ? m->D : m->M;
-    a.nbatches = (N + 31) / 32;
-    a.queue = m->queue + (size_t)(m->next_slot++ % 16) * (QUEUE_BYTES / sizeof(uint32_t));
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, s);
-    if (e != hipSuccess) return e;
-    const uint64_t wgs = (a.nbatches + 7) / 8;
-    m->launch(a, lambda, (unsigned)(wgs < 256 ? wgs : 256), s);
+    if (lambda && m->nblocks != 1) return hipErrorInvalidValue;
+    for (uint32_t b = 0; b < m->nblocks; ++b) {
+        const uint32_t rows = std::min(128u, m->M - 128 * b), R2 = block_width(rows);
+        LongProjectArgs a;
+        a.X = dX; a.N = N; a.D = m->D; a.M = rows;
+        a.pieces1 = m->pieces1 + b * m->block_floats; a.pieces2 = m->pieces2;
+        a.Y = dY + 128 * b; a.ldy = lambda ? m->D : m->M;
+        a.nbatches = (N + 31) / 32;
+        a.queue = m->queue + (size_t)(m->next_slot++ % 16) * (QUEUE_BYTES / sizeof(uint32_t));
+        const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, s);
+        if (e != hipSuccess) return e;
+        const uint64_t wgs = (a.nbatches + 7) / 8;
+        const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+        if (R2 == 32) launch_project_long<32>(a, lambda, grid, s);
+        else if (R2 == 64) launch_project_long<64>(a, lambda, grid, s);
+        else launch_project_long<128>(a, lambda, grid, s);
+    }
     return hipGetLastError();
 }
 

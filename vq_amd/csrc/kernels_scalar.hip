@@ -153,6 +153,12 @@ k_project_local_bwd(const float *__restrict__ T, uint64_t N, uint32_t D, const f
     }
 }
 
+__global__ void __launch_bounds__(256) k_square(float *d, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = d[i] * d[i];
+}
+
 inline unsigned grid_for(uint64_t work)
 {
     uint64_t blocks = (work + 255) / 256;
@@ -186,6 +192,13 @@ hipError_t launch_assign_scalar_f64(const double *dX, uint64_t N, uint32_t D, co
     else
         hipLaunchKernelGGL((k_assign_scalar<false, double, Outputs64>), dim3(grid_for(N)), dim3(256), 0, s, dX, N, D, dW,
                            K, dcls, dy, 1, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_square(float *d, uint64_t n, hipStream_t s)
+{
+    if (n == 0 || !d) return hipSuccess;
+    hipLaunchKernelGGL(k_square, dim3(grid_for(n)), dim3(256), 0, s, d, n);
     return hipGetLastError();
 }
 

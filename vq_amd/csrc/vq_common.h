@@ -85,6 +85,9 @@ struct LongProjectModel;
 LongProjectModel *long_project_build(const std::vector<float> &Om, uint32_t M, uint32_t D, hipError_t &herr);
 void long_project_free(LongProjectModel *m);
 hipError_t long_project_run(const LongProjectModel *m, const float *dX, uint64_t N, bool lambda, float *dY, hipStream_t s);
+bool long_project_has_lambda(const LongProjectModel *m);     // project (Lambda): Omega of at most 128 rows
+// d[i] = d[i]^2 (rooted Euclidean distances of a search in the projected space -> helpers.rs:44)
+hipError_t launch_square(float *d, uint64_t n, hipStream_t s);
 
 // LGMLVQ::project on the matrix cores (kernels_project.hip): samples grouped by winner, Lambda_j from L2
 struct LocalProjectModel;
