@@ -845,12 +845,15 @@ def test_long_rows(ctx, case):
         assert rep.ok, f"{case} matching={matching}: {rep}"
 
 
-@pytest.mark.parametrize("case", [(300, 300, 20, 300), (200, 784, 10, 200), (150, 400, 300, 129), (100, 512, 5, 513), (65, 260, 3, 260)],
+@pytest.mark.parametrize("case", [(300, 300, 20, 300), (200, 784, 10, 200), (150, 400, 300, 129), (100, 512, 5, 513), (65, 260, 3, 260),
+                                  # rows of at most 256 values whose Omega no single-pass kernel holds
+                                  (300, 200, 20, 200), (200, 150, 300, 150), (100, 64, 5, 300), (150, 256, 10, 128)],
                          ids=lambda c: "n%d_d%d_k%d_m%d" % c)
-def test_long_rows_tall_omega(ctx, case):
-    """A global Omega with more than 128 rows over rows above 256 values (GMLVQ's square Omega on long rows): two
-    passes -- k_project_long in blocks of 128 Omega rows into scratch, a Euclidean engine over W Omega^T in the
-    projected space, distances squared -- against the oracle, plain and matched, NaN / INF rows, project_omega."""
+def test_two_pass_omega(ctx, case):
+    """A global Omega no single-pass kernel holds (GMLVQ's square Omega on rows of 129..256 or above 256 values, more
+    than 256 Omega rows): two passes -- k_project_long (blocks of 128 Omega rows) or k_project into scratch, a
+    Euclidean engine over W Omega^T in the projected space, distances squared -- against the oracle, plain and
+    matched, NaN / INF rows, project_omega."""
     import torch
     from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
     N, D, K, M = case
@@ -891,10 +894,10 @@ def test_long_rows_tall_omega(ctx, case):
     Xc = X[:N].copy()
     Xc[~np.isfinite(Xc)] = 0.5
     Z = ctx.project(Xc, PROJECT_OMEGA)
-    assert ctx.last_kernel == "mfma_project_long"
+    assert ctx.last_kernel == ("mfma_project_long" if D > 256 else "mfma_project")
     assert _rel_err(Z, oracle.project_omega(Om, Xc)) < 1e-5
-    Y = ctx.project(Xc, PROJECT_LAMBDA)                                   # needs all of Omega x at once: scalar kernels
-    assert ctx.last_kernel == "scalar_project"
+    Y = ctx.project(Xc, PROJECT_LAMBDA)           # long rows: needs all of Omega x at once, scalar kernels above 128 Omega rows
+    assert ctx.last_kernel == ("scalar_project" if D > 256 else "mfma_project")
     assert _rel_err(Y, oracle.project_lambda(Om, Xc)) < 1e-5
 
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <new>
@@ -50,9 +51,10 @@ struct vqhip_ctx {
     hipEvent_t scratch_done = nullptr;
 
     EngineModel *engine = nullptr;
-    // A global Omega the single-pass kernels do not hold (more than 128 rows over rows above 256 values): the samples
-    // are projected into scratch (k_project_long, blocks of 128 Omega rows) and searched there by a Euclidean
-    // engine over P = W Omega^T; the rooted distances are squared afterwards (helpers.rs:44).
+    // A global Omega no single-pass kernel holds (more than 128 rows over rows above 256 values; more than 64 rows
+    // over 129..256 values; more than 256 rows): the samples are projected into scratch (k_project_long / k_project)
+    // and searched there by a Euclidean engine over P = W Omega^T; the rooted distances are squared afterwards
+    // (helpers.rs:44).
     EngineModel *engine2 = nullptr;
     std::vector<float> hP;     // K x M: W . Omega^T (global Omega only)
     bool engine_tried = false;
@@ -154,10 +156,10 @@ int prepare_engine(vqhip_ctx *c)
         c->engine = engine_build(c->hW, c->K, c->D, c->hOm, c->omega_kind, c->M, c->hcls, c->engine_why, herr);
         if (herr != hipSuccess) return c->fail_hip(herr, "engine_build");
     }
-    if (!c->engine && !c->engine2 && c->omega_kind == OMEGA_GLOBAL && c->D > 256 && c->M > 128) {
+    if (!c->engine && !c->engine2 && c->omega_kind == OMEGA_GLOBAL && !getenv("VQHIP_NO_TWO_PASS")) {
         int rc = prepare_project(c);
         if (rc != VQHIP_OK) return rc;
-        if (c->proj_long) {
+        if (c->proj_long || c->proj_omega) {
             hipError_t herr = hipSuccess;
             std::string why2;
             c->engine2 = engine_build(c->hP, c->K, c->M, std::vector<float>(), OMEGA_NONE, 0, c->hcls, why2, herr);
@@ -201,7 +203,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
         return VQHIP_OK;
     }
 
-    if (c->engine2 && c->proj_long && c->policy != VQHIP_KERNEL_SCALAR && ((uintptr_t)dX & 3) == 0) {
+    if (c->engine2 && (c->proj_long || c->proj_omega) && c->policy != VQHIP_KERNEL_SCALAR && ((uintptr_t)dX & 3) == 0) {
         const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (256ull << 20) / (c->M * 4ull)));
         if (c->dYproj_cap < chunk * c->M) {
             HIPCHK(c, hipStreamSynchronize(s));
@@ -219,7 +221,10 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
             if (o.dist) o.dist += off;
             if (o.jneg) o.jneg += off;
             if (o.dneg) o.dneg += off;
-            HIPCHK(c, long_project_run(c->proj_long, dX + off * c->D, n, false, c->dYproj, s));
+            if (c->proj_long)
+                HIPCHK(c, long_project_run(c->proj_long, dX + off * c->D, n, false, c->dYproj, s));
+            else
+                HIPCHK(c, project_run(c->proj_omega, dX + off * c->D, n, c->dYproj, c->M, s));
             HIPCHK(c, engine_assign(c->engine2, c->dYproj, n, dy ? dy + off : nullptr, o, s));
             HIPCHK(c, launch_square(o.dist, n, s));
             if (dy) HIPCHK(c, launch_square(o.dneg, n, s));
