@@ -896,8 +896,8 @@ def test_two_pass_omega(ctx, case):
     Z = ctx.project(Xc, PROJECT_OMEGA)
     assert ctx.last_kernel == ("mfma_project_long" if D > 256 else "mfma_project")
     assert _rel_err(Z, oracle.project_omega(Om, Xc)) < 1e-5
-    Y = ctx.project(Xc, PROJECT_LAMBDA)           # long rows: needs all of Omega x at once, scalar kernels above 128 Omega rows
-    assert ctx.last_kernel == ("scalar_project" if D > 256 else "mfma_project")
+    Y = ctx.project(Xc, PROJECT_LAMBDA)           # long rows and more than 128 Omega rows: Omega x, then Omega^T y
+    assert ctx.last_kernel == ("mfma_project_two_pass" if D > 256 else "mfma_project")
     assert _rel_err(Y, oracle.project_lambda(Om, Xc)) < 1e-5
 
 

@@ -62,6 +62,10 @@ struct vqhip_ctx {
     ProjectModel *proj_omega = nullptr, *proj_lambda = nullptr;   // matrix-core projections (global Omega)
     LocalProjectModel *proj_local = nullptr;                      // LGMLVQ::project (local Omegas)
     LongProjectModel *proj_long = nullptr;                        // global Omega over rows above 256 values
+    // ... with more than 128 rows: project (Lambda) = Omega^T (Omega x) in two passes, the second with Omega^T
+    // (D rows of M values) as the matrix, through whichever projection kernel holds rows of M values
+    ProjectModel *proj_back = nullptr;
+    LongProjectModel *proj_back_long = nullptr;
     bool proj_tried = false;
 
     Staging st[2];
@@ -99,7 +103,10 @@ void drop_engine(vqhip_ctx *c)
     project_free(c->proj_lambda);
     local_project_free(c->proj_local);
     long_project_free(c->proj_long);
-    c->proj_long = nullptr;
+    long_project_free(c->proj_back_long);
+    project_free(c->proj_back);
+    c->proj_long = c->proj_back_long = nullptr;
+    c->proj_back = nullptr;
     c->proj_omega = c->proj_lambda = nullptr;
     c->proj_local = nullptr;
     c->proj_tried = false;
@@ -204,7 +211,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
     }
 
     if (c->engine2 && (c->proj_long || c->proj_omega) && c->policy != VQHIP_KERNEL_SCALAR && ((uintptr_t)dX & 3) == 0) {
-        const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (256ull << 20) / (c->M * 4ull)));
+        const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (1024ull << 20) / (c->M * 4ull)));
         if (c->dYproj_cap < chunk * c->M) {
             HIPCHK(c, hipStreamSynchronize(s));
             (void)hipFree(c->dYproj);
@@ -385,6 +392,16 @@ int prepare_project(vqhip_ctx *c)
     if (c->D > 256) {
         c->proj_long = long_project_build(c->hOm, c->M, c->D, herr);
         if (herr != hipSuccess) return c->fail_hip(herr, "long_project_build");
+        if (c->proj_long && !long_project_has_lambda(c->proj_long)) {
+            std::vector<float> OmT((size_t)c->D * c->M);
+            for (uint32_t m = 0; m < c->M; ++m)
+                for (uint32_t d = 0; d < c->D; ++d) OmT[(size_t)d * c->M + m] = c->hOm[(size_t)m * c->D + d];
+            if (c->M <= 256)
+                c->proj_back = project_build(OmT, c->D, c->M, herr);
+            else
+                c->proj_back_long = long_project_build(OmT, c->D, c->M, herr);
+            if (herr != hipSuccess) return c->fail_hip(herr, "project_build (Omega^T)");
+        }
         return VQHIP_OK;
     }
     c->proj_omega = project_build(c->hOm, c->M, c->D, herr);
@@ -436,6 +453,22 @@ int project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *
             c->last_kernel = "mfma_project_long";
             HIPCHK(c, long_project_run(c->proj_long, dX, N, which == VQHIP_PROJECT_LAMBDA, dY, s));
             return VQHIP_OK;
+        }
+        if (c->proj_long && (c->proj_back || c->proj_back_long) && ((uintptr_t)dY & 3) == 0 && ((uintptr_t)dX & 3) == 0) {
+            // Lambda x = Omega^T (Omega x), chunks of rows through an N x M intermediate
+            const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (1024ull << 20) / (c->M * 4ull)));
+            if ((rc = ensure_proj_scratch(c, (size_t)chunk * c->M, s)) != VQHIP_OK) return rc;
+            if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
+            for (uint64_t off = 0; off < N; off += chunk) {
+                const uint64_t n = std::min(chunk, N - off);
+                HIPCHK(c, long_project_run(c->proj_long, dX + off * c->D, n, false, c->dProj, s));
+                if (c->proj_back)
+                    HIPCHK(c, project_run(c->proj_back, c->dProj, n, dY + off * c->D, c->D, s));
+                else
+                    HIPCHK(c, long_project_run(c->proj_back_long, c->dProj, n, false, dY + off * c->D, s));
+            }
+            c->last_kernel = "mfma_project_two_pass";
+            return scratch_release(c, s);
         }
     }
     if (c->omega_kind == OMEGA_LOCAL && c->policy != VQHIP_KERNEL_SCALAR && c->proj_local && ((uintptr_t)dY & 3) == 0 &&
