@@ -719,6 +719,103 @@ def test_shape_sweep_against_oracle(ctx, shape):
             assert rep.ok, f"{shape} {ctx.last_kernel} matching={matching}: {rep}"
 
 
+def test_global_omega_dispatch_grid(ctx):
+    """Every (D, M, K) on a grid around the kernels' boundaries (D 32..300, Omega rows 1..300) is served by a
+    matrix-core kernel under VQHIP_KERNEL_AUTO and agrees with the scalar kernels on the device: same winner wherever
+    the scalar runner-up is not within 1e-4, distances within 1e-5 relative (+2e-6)."""
+    import torch
+    rng = np.random.default_rng(2024)
+    N = 160
+    seen = set()
+    for D in (32, 100, 128, 129, 200, 256, 257, 300):
+        X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+        Xd = torch.from_numpy(X).cuda()
+        for M in (1, 16, 17, 64, 65, 128, 129, 256, 257, 300):
+            Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+            for K in (2, 40, 257):
+                W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+                out = {}
+                for policy in (KERNEL_SCALAR, KERNEL_AUTO):
+                    ctx.set_kernel_policy(policy)
+                    ctx.set_prototypes(W)
+                    ctx.set_omega(Om)
+                    idx = torch.empty(N, dtype=torch.int32, device="cuda")
+                    dist = torch.empty(N, dtype=torch.float32, device="cuda")
+                    ctx.assign_into(Xd, idx, dist)
+                    torch.cuda.synchronize()
+                    out[policy] = (idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64), ctx.last_kernel)
+                si, sd, sk = out[KERNEL_SCALAR]
+                ai, ad, ak = out[KERNEL_AUTO]
+                # dozens of prototypes projected onto a line: some triple lies closer together than the f32 screening resolves (scalar by design)
+                dense = M == 1 and K >= 40
+                assert sk == "scalar" and (ak.startswith("mfma_omega") or (dense and ak == "scalar")), (D, M, K, sk, ak)
+                seen.add(ak)
+                # distances first: a different winner within tolerance shows up as a near-equal distance
+                assert np.all(np.abs(ad - sd) <= 1e-4 * np.abs(sd) + 2e-6), (D, M, K, ak, float(np.abs(ad - sd).max()))
+                same = ai == si
+                assert same.mean() > 0.97, (D, M, K, ak, float(same.mean()))
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    assert {"mfma_omega_lds", "mfma_omega_lowrank_lds", "mfma_omega", "mfma_omega_long", "mfma_omega_two_pass"} <= seen, seen
+
+
+def _auto_vs_scalar(ctx, Xd, N, load, what, prefix, rtol=1e-4, atol=2e-6, dense_ok=False):
+    """One model under both policies on the device; returns the AUTO kernel's name.  dense_ok: the model may be one
+    the library keeps on the scalar kernels because its prototypes lie closer to each other than the f32 screening
+    resolves (engine_host.hip second_neighbour_gap)."""
+    import torch
+    out = {}
+    for policy in (KERNEL_SCALAR, KERNEL_AUTO):
+        ctx.set_kernel_policy(policy)
+        load()
+        idx = torch.empty(N, dtype=torch.int32, device="cuda")
+        dist = torch.empty(N, dtype=torch.float32, device="cuda")
+        ctx.assign_into(Xd, idx, dist)
+        torch.cuda.synchronize()
+        out[policy] = (idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64), ctx.last_kernel)
+    si, sd, sk = out[KERNEL_SCALAR]
+    ai, ad, ak = out[KERNEL_AUTO]
+    assert sk == "scalar" and (ak.startswith(prefix) or (dense_ok and ak == "scalar")), (what, sk, ak)
+    assert np.all(np.abs(ad - sd) <= rtol * np.abs(sd) + atol), (what, ak, float(np.abs(ad - sd).max()))
+    assert (ai == si).mean() > 0.97, (what, ak, float((ai == si).mean()))
+    return ak
+
+
+def test_euclid_and_local_dispatch_grids(ctx):
+    """As test_global_omega_dispatch_grid, for Euclidean models (D 1..1000, K 1..5000) and local Omegas (D 16..400,
+    1..130 rows each): no shape on the grids falls back to the scalar kernels, and both agree on the device."""
+    import torch
+    rng = np.random.default_rng(77)
+    N = 160
+    seen = set()
+    for D in (1, 3, 16, 31, 64, 100, 128, 200, 256, 257, 500, 1000):
+        X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+        Xd = torch.from_numpy(X).cuda()
+        for K in (1, 2, 33, 256, 257, 1000, 5000):
+            if D > 256 and K > 4096:
+                continue                                               # scalar by design (DESIGN 4.6)
+            W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+            # hundreds of random prototypes on a line or in space: some triple lies within 1e-3 of each other
+            dense = (D == 1 and K >= 256) or (D == 3 and K >= 1000)
+            ak = _auto_vs_scalar(ctx, Xd, N, lambda: ctx.set_prototypes(W), (D, K), "mfma_euclid", rtol=1e-5, atol=1e-7, dense_ok=dense)
+            if D == 1 and K == 5000:
+                assert ak == "scalar"                                  # 5000 prototypes in [-1, 1): 4e-4 apart
+            seen.add(ak)
+    for D in (16, 100, 128, 200, 256, 300, 400):
+        X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+        Xd = torch.from_numpy(X).cuda()
+        for M in (1, 32, 33, 130):
+            for K in (1, 3, 20):
+                W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+                Oms = (rng.uniform(-1, 1, size=(K, M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+
+                def load():
+                    ctx.set_prototypes(W)
+                    ctx.set_local_omegas(Oms)
+                seen.add(_auto_vs_scalar(ctx, Xd, N, load, (D, M, K), "mfma_local"))
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    assert {"mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local", "mfma_local_long"} <= seen, seen
+
+
 @pytest.mark.parametrize("case", [(5000, 128, 32), (3001, 64, 64), (2500, 64, 7), (1999, 32, 50)], ids=lambda c: "n%d_d%d_k%d" % c)
 def test_staged_kernel(ctx, case):
     """Few prototypes: rows staged through LDS by 1 KiB LDS-DMA pieces (2 / 4 / 8 rows per piece at D = 128 / 64 / 32).

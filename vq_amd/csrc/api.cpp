@@ -57,7 +57,7 @@ struct vqhip_ctx {
     // (helpers.rs:44).
     EngineModel *engine2 = nullptr;
     std::vector<float> hP;     // K x M: W . Omega^T (global Omega only)
-    bool engine_tried = false;
+    bool engine_tried = false, engine2_tried = false;
     std::string engine_why;
     ProjectModel *proj_omega = nullptr, *proj_lambda = nullptr;   // matrix-core projections (global Omega)
     LocalProjectModel *proj_local = nullptr;                      // LGMLVQ::project (local Omegas)
@@ -97,7 +97,7 @@ void drop_engine(vqhip_ctx *c)
     engine_free(c->engine);
     engine_free(c->engine2);
     c->engine = c->engine2 = nullptr;
-    c->engine_tried = false;
+    c->engine_tried = c->engine2_tried = false;
     c->engine_why.clear();
     project_free(c->proj_omega);
     project_free(c->proj_lambda);
@@ -163,7 +163,8 @@ int prepare_engine(vqhip_ctx *c)
         c->engine = engine_build(c->hW, c->K, c->D, c->hOm, c->omega_kind, c->M, c->hcls, c->engine_why, herr);
         if (herr != hipSuccess) return c->fail_hip(herr, "engine_build");
     }
-    if (!c->engine && !c->engine2 && c->omega_kind == OMEGA_GLOBAL && !getenv("VQHIP_NO_TWO_PASS")) {
+    if (!c->engine && !c->engine2_tried && c->omega_kind == OMEGA_GLOBAL && !getenv("VQHIP_NO_TWO_PASS")) {
+        c->engine2_tried = true;
         int rc = prepare_project(c);
         if (rc != VQHIP_OK) return rc;
         if (c->proj_long || c->proj_omega) {

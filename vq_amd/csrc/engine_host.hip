@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <cstring>
 
 #include "mfma_device.h"
@@ -72,6 +73,41 @@ void find_duplicates(const std::vector<float> &Q, uint32_t K, uint32_t L, std::v
         first = std::move(f);
         next = std::move(n);
     }
+}
+
+// Screening works on scores ||w||^2 - 2 x.w in f32 (error about 2e-6 of the norm scale once the keys' 4 mantissa
+// bits are dropped) and re-measures the best TWO candidates in the direct form.  A sample next to three or more
+// prototypes that lie closer to each other than that error can have its true winner outside the two: such models
+// are left to the scalar kernels (direct form throughout).  Returns the smallest squared distance from a prototype
+// to its second-nearest distinct neighbour, or -1 when the pairwise pass would be too long for the host (then the
+// model is taken as it is).
+double second_neighbour_gap(const std::vector<float> &Q, uint32_t K, uint32_t L)
+{
+    if (K < 3 || (double)K * K * L > 4e8) return -1.0;
+    const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<double> best(nthreads, INFINITY);
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nthreads; ++w)
+        pool.emplace_back([&, w] {
+            for (uint32_t i = w; i < K; i += nthreads) {
+                double q1 = INFINITY, q2 = INFINITY;
+                const float *a = &Q[(size_t)i * L];
+                for (uint32_t j = 0; j < K; ++j) {
+                    if (j == i) continue;
+                    const float *b = &Q[(size_t)j * L];
+                    double t = 0.0;
+                    for (uint32_t d = 0; d < L && t < q2; ++d) {
+                        const double df = (double)a[d] - (double)b[d];
+                        t += df * df;
+                    }
+                    if (!(t > 0.0)) continue;                      // identical rows tie bit for bit: settle_ties
+                    if (t < q1) { q2 = q1; q1 = t; } else if (t < q2) q2 = t;
+                }
+                if (q2 < best[w]) best[w] = q2;
+            }
+        });
+    for (std::thread &t : pool) t.join();
+    return *std::min_element(best.begin(), best.end());
 }
 
 int variant_env()
@@ -381,6 +417,13 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
             // The screening form needs ||p||^2 and 2 p.x inside f32 range; the scalar kernels do not.
             if (!(t < 1e37)) {
                 why = "a prototype's squared norm is not finite in f32";
+                return nullptr;
+            }
+        }
+        {
+            const double gap = second_neighbour_gap(Q, K, L);
+            if (gap >= 0.0 && gap < 1.6e-5 * 2.0 * std::max(wmax2, 1e-300) && !getenv("VQHIP_DENSE_OK")) {
+                why = "three or more prototypes closer to each other than the f32 screening resolves";
                 return nullptr;
             }
         }
