@@ -160,7 +160,7 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
 bool bind_long(EngineModel &m, std::vector<float> &img1, std::vector<float> &img2, const std::vector<float> &W,
                const std::vector<float> &norms, const std::vector<uint32_t> &cls)
 {
-    if (m.D <= 256 || m.K > 4096) return false;
+    if (m.D <= 256 || (uint64_t)(m.K + 255) * (m.D + 127) * 4 >= (1ull << 31)) return false;   // pieces: 32-bit byte offsets
     const uint32_t rt = res_tiles(m.K), tiles = rt <= 2 ? rt : (rt <= 4 ? 4 : 8), groups = (rt + tiles - 1) / tiles;
     const uint32_t steps = tiles <= 2 ? 16 : 8, chunk = steps * 8;     // as in the kernel: 128-value chunks up to 2 tiles, else 64
     const uint32_t NC = (m.D + chunk - 1) / chunk;
@@ -375,10 +375,10 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                           hipError_t &herr)
 {
     herr = hipSuccess;
-    if (D > 256 && !(((omega_kind == OMEGA_NONE && K <= 4096) || (omega_kind == OMEGA_GLOBAL && M <= 128) ||
+    if (D > 256 && !(((omega_kind == OMEGA_NONE && (uint64_t)(K + 255) * (D + 127) * 4 < (1ull << 31)) || (omega_kind == OMEGA_GLOBAL && M <= 128) ||
                        (omega_kind == OMEGA_LOCAL && (uint64_t)K * ((M + 31) / 32) <= 2048)) && D <= 65536 &&
                      !getenv("VQHIP_NO_LONG"))) {
-        why = "sample length above 256 (served for Euclidean models with at most 4096 prototypes, a global Omega of at most 128 rows, local Omegas of at most 2048 tiles of 32 rows)";
+        why = "sample length above 256 (served for Euclidean models whose prototypes take less than 2 GiB, a global Omega of at most 128 rows, local Omegas of at most 2048 tiles of 32 rows)";
         return nullptr;
     }
     if (omega_kind != OMEGA_NONE && M > 256) {
