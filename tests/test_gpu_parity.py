@@ -274,6 +274,15 @@ def test_host_path_multi_chunk_shared_scratch_and_queues(ctx):
         o = oracle.assign(X[lo:lo + 2000], m.W, omega=m.omega, threads=8)
         rep = parity.compare(idx[lo:lo + 2000], dist[lo:lo + 2000], *o, atol=2e-6)
         assert rep.ok, f"rows {lo}..: {rep}"
+    m = _model(("t", "GMLVQ", 1, 300, 6, 200, "global"))              # two passes through the shared projected-sample scratch
+    X = synth.samples_host(m, 0, N)
+    synth.load_model(ctx, m, with_labels=False)
+    idx, dist = ctx.assign(X)
+    assert ctx.last_kernel == "mfma_omega_two_pass"
+    for lo in (0, N // 3, N // 2 - 300, N - 2000):
+        o = oracle.assign(X[lo:lo + 2000], m.W, omega=m.omega, threads=8)
+        rep = parity.compare(idx[lo:lo + 2000], dist[lo:lo + 2000], *o, atol=2e-6)
+        assert rep.ok, f"two-pass rows {lo}..: {rep}"
     m = _model(("t", "GLVQ", 1, 16, 40, 0, "none"))                   # D = 16: pipelined kernel, 2M-row chunks
     N = (128 << 20) // 64 * 3 + 99
     X = synth.samples_host(m, 0, N)

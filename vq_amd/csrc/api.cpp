@@ -196,6 +196,19 @@ int scratch_release(vqhip_ctx *c, hipStream_t s)
     return VQHIP_OK;
 }
 
+// The scratch for projected samples holds at least `need` floats (grown after the stream has drained).
+int ensure_yproj(vqhip_ctx *c, size_t need, hipStream_t s)
+{
+    if (c->dYproj_cap >= need) return VQHIP_OK;
+    HIPCHK(c, hipStreamSynchronize(s));
+    (void)hipFree(c->dYproj);
+    c->dYproj = nullptr;
+    c->dYproj_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&c->dYproj, need * sizeof(float)));
+    c->dYproj_cap = need;
+    return VQHIP_OK;
+}
+
 // All kernels for one device-resident batch, enqueued on `s`.
 int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s)
 {
@@ -213,14 +226,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
 
     if (c->engine2 && (c->proj_long || c->proj_omega) && c->policy != VQHIP_KERNEL_SCALAR && ((uintptr_t)dX & 3) == 0) {
         const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (1024ull << 20) / (c->M * 4ull)));
-        if (c->dYproj_cap < chunk * c->M) {
-            HIPCHK(c, hipStreamSynchronize(s));
-            (void)hipFree(c->dYproj);
-            c->dYproj = nullptr;
-            c->dYproj_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->dYproj, chunk * c->M * sizeof(float)));
-            c->dYproj_cap = chunk * c->M;
-        }
+        if ((rc = ensure_yproj(c, chunk * c->M, s)) != VQHIP_OK) return rc;
         if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
         for (uint64_t off = 0; off < N; off += chunk) {
             const uint64_t n = std::min(chunk, N - off);
@@ -247,14 +253,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
     } else if (c->omega_kind == OMEGA_GLOBAL) {
         // Project a chunk of samples into the M-dim space, then search there against W.Omega^T.
         const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1, (64ull << 20) / (c->M * 4ull)));
-        if (c->dYproj_cap < chunk * c->M) {
-            HIPCHK(c, hipStreamSynchronize(s));
-            (void)hipFree(c->dYproj);
-            c->dYproj = nullptr;
-            c->dYproj_cap = 0;
-            HIPCHK(c, hipMalloc((void **)&c->dYproj, chunk * c->M * sizeof(float)));
-            c->dYproj_cap = chunk * c->M;
-        }
+        if ((rc = ensure_yproj(c, chunk * c->M, s)) != VQHIP_OK) return rc;
         if ((rc = scratch_acquire(c, s)) != VQHIP_OK) return rc;
         for (uint64_t off = 0; off < N; off += chunk) {
             const uint64_t n = std::min(chunk, N - off);
