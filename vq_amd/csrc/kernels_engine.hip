@@ -270,15 +270,11 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                                     const uint32_t key = pack_key(acc[s][o], o);
                                     const bool match = cls == lab[s];                 // helpers.rs:113 / :122
                                     const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
-                                    km[s].p = kmin(km[s].p, kp);
-                                    km[s].n = kmin(km[s].n, kn);
+                                    offer_m(km[s], kp, kn);
                                 }
                             });
 #pragma unroll
-                            for (int s = 0; s < S; ++s) {
-                                km[s].tp = km[s].p != om[s].p ? tile_id : om[s].tp;
-                                km[s].tn = km[s].n != om[s].n ? tile_id : om[s].tn;
-                            }
+                            for (int s = 0; s < S; ++s) settle_tiles_m(km[s], om[s], tile_id);
                         }
                     }
                 }
@@ -300,16 +296,8 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     return ROOT ? sqrtf(d) : d;
                 };
                 if (!MATCHED) {
-                    const uint32_t k1 = key_row(ku[s].b1, ku[s].t1, h), k2 = key_row(ku[s].b2, ku[s].t2, h);
-                    const uint32_t pb1 = xor32(ku[s].b1), pb2 = xor32(ku[s].b2), pk1 = xor32(k1), pk2 = xor32(k2);
                     uint32_t f, fi, sd, si;                            // best two of the pair's four, by (key, index)
-                    if (keyless(pb1, pk1, ku[s].b1, k1)) {
-                        f = pb1; fi = pk1;
-                        if (keyless(ku[s].b1, k1, pb2, pk2)) { sd = ku[s].b1; si = k1; } else { sd = pb2; si = pk2; }
-                    } else {
-                        f = ku[s].b1; fi = k1;
-                        if (keyless(pb1, pk1, ku[s].b2, k2)) { sd = pb1; si = pk1; } else { sd = ku[s].b2; si = k2; }
-                    }
+                    merge_pair(ku[s].b1, ku[s].t1, ku[s].b2, ku[s].t2, h, f, fi, sd, si);
                     if (key_valid(f) && !rescan) {
                         const float d1 = measure(fi);
                         wp.d = d1; wp.i = fi;
@@ -322,18 +310,22 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                         rescan = true;
                     }
                 } else {
-                    uint32_t kp = key_row(km[s].p, km[s].tp, h), kn = key_row(km[s].n, km[s].tn, h), p = km[s].p, n = km[s].n;
-                    const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
-                    if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
-                    if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
-                    if (key_valid(p)) {
-                        wp.d = measure(kp); wp.i = kp;
-                        rescan |= !(wp.d < INFINITY);
-                    }
-                    if (key_valid(n)) {
-                        wn.d = measure(kn); wn.i = kn;
-                        rescan |= !(wn.d < INFINITY);
-                    }
+                    // each class group like the unlabelled search: best two of the pair's four, both re-measured
+                    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, Best1 &w) {
+                        uint32_t f, fi, sd, si;
+                        merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
+                        if (key_valid(f)) {
+                            const float d1 = measure(fi);
+                            w.d = d1; w.i = fi;
+                            if (key_valid(sd)) {
+                                const float d2 = measure(si);
+                                if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
+                            }
+                            rescan |= !(w.d < INFINITY);
+                        }
+                    };
+                    group(km[s].p, km[s].tp, km[s].p2, km[s].tp2, wp);
+                    group(km[s].n, km[s].tn, km[s].n2, km[s].tn2, wn);
                 }
                 if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn);
                 settle_ties<MATCHED>(a, lab[s], wp, wn);

@@ -201,8 +201,9 @@ constexpr float KEY_VALID_F = 1.0e38f;               // keys of real prototypes 
 struct Keys2 {                       // unlabelled search: best two keys and their tiles
     uint32_t b1 = KEY_NONE, b2 = KEY_NONE, t1 = 0u, t2 = 0u;
 };
-struct KeysM {                       // labelled search: best key with cls == y, best with cls != y
+struct KeysM {                       // labelled search: best two keys with cls == y, best two with cls != y, their tiles
     uint32_t p = KEY_NONE, n = KEY_NONE, tp = 0u, tn = 0u;
+    uint32_t p2 = KEY_NONE, n2 = KEY_NONE, tp2 = 0u, tn2 = 0u;
 };
 __device__ __forceinline__ bool key_valid(uint32_t key) { return __builtin_bit_cast(float, key) < KEY_VALID_F; }
 
@@ -217,6 +218,21 @@ __device__ __forceinline__ uint32_t kmin(uint32_t x, uint32_t y)                
     uint32_t r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
+}
+__device__ __forceinline__ uint32_t kmed3(uint32_t x, uint32_t y, uint32_t z)        // median as floats
+{
+    uint32_t r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+// One key offered to the labelled search: kp is the key where the row's class matches the sample's label (else
+// KEY_NONE), kn the other way round; each group keeps its best two (the runner-up is re-measured where it is close).
+__device__ __forceinline__ void offer_m(KeysM &km, uint32_t kp, uint32_t kn)
+{
+    km.p2 = kmed3(km.p, km.p2, kp);
+    km.p = kmin(km.p, kp);
+    km.n2 = kmed3(km.n, km.n2, kn);
+    km.n = kmin(km.n, kn);
 }
 // The 16 scores of one finished tile offered to the lane's best two keys: position bits in, median, minimum
 // (3 VALU per score).  One asm statement: the compiler pads a wait state behind every inline-asm result
@@ -288,6 +304,22 @@ __device__ __forceinline__ void settle_tiles(Keys2 &ku, const Keys2 &before, uin
     ku.t1 = c1 ? tile_id : before.t1;
 }
 
+__device__ __forceinline__ void settle_tiles_m(KeysM &km, const KeysM &before, uint32_t tile_id)
+{
+    {
+        const bool c1 = km.p != before.p, c2 = km.p2 != before.p2;
+        const uint32_t demoted = km.p2 == before.p ? before.tp : tile_id;
+        km.tp2 = c1 ? demoted : (c2 ? tile_id : before.tp2);
+        km.tp = c1 ? tile_id : before.tp;
+    }
+    {
+        const bool c1 = km.n != before.n, c2 = km.n2 != before.n2;
+        const uint32_t demoted = km.n2 == before.n ? before.tn : tile_id;
+        km.tn2 = c1 ? demoted : (c2 ? tile_id : before.tn2);
+        km.tn = c1 ? tile_id : before.tn;
+    }
+}
+
 __device__ __forceinline__ uint32_t key_row(uint32_t key, uint32_t tile, int h)   // prototype index of a key
 {
     const uint32_t o = key & 15u;
@@ -298,6 +330,22 @@ __device__ __forceinline__ bool keyless(uint32_t ak, uint32_t ai, uint32_t bk, u
 {
     const float a = __builtin_bit_cast(float, ak), b = __builtin_bit_cast(float, bk);
     return a < b || (a == b && ai < bi);
+}
+
+// The lane pair (h = 0 / 1) of a sample agrees on the best two of its four candidates, by (key, prototype index):
+// (f, fi) the best key and its prototype, (sd, si) the runner-up.
+__device__ __forceinline__ void merge_pair(uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, int h, uint32_t &f, uint32_t &fi,
+                                           uint32_t &sd, uint32_t &si)
+{
+    const uint32_t k1 = key_row(b1, t1, h), k2 = key_row(b2, t2, h);
+    const uint32_t pb1 = xor32(b1), pb2 = xor32(b2), pk1 = xor32(k1), pk2 = xor32(k2);
+    if (keyless(pb1, pk1, b1, k1)) {
+        f = pb1; fi = pk1;
+        if (keyless(b1, k1, pb2, pk2)) { sd = b1; si = k1; } else { sd = pb2; si = pk2; }
+    } else {
+        f = b1; fi = k1;
+        if (keyless(pb1, pk1, b2, k2)) { sd = pb1; si = pk1; } else { sd = b2; si = k2; }
+    }
 }
 
 // Chunk c = 2j + h of a row of D floats fetched as 16 bytes: values at or past D belong to the next row (or are
@@ -484,13 +532,9 @@ __device__ __forceinline__ void half_step(const float *tile, const float *next, 
                 }
                 const bool match = cgc[o & 3] == label;           // helpers.rs:113 / :122
                 const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
-                km.p = kmin(km.p, kp);
-                km.n = kmin(km.n, kn);
+                offer_m(km, kp, kn);
             });
-            if constexpr (o0 < 16 && o1 == 16) {          // all 16 keys of the tile are in: settle the tiles
-                km.tp = km.p != om.p ? tprev_id : om.tp;
-                km.tn = km.n != om.n ? tprev_id : om.tn;
-            }
+            if constexpr (o0 < 16 && o1 == 16) settle_tiles_m(km, om, tprev_id);   // all 16 keys of the tile are in
         }
         if constexpr (i == CI) {
             const float *tail = next + Gm::W_FLOATS;
@@ -522,11 +566,9 @@ __device__ __forceinline__ void last_screen(const f32x16 &prev, const float *tpr
             const uint32_t key = pack_key(prev[o], o);
             const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;
             const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
-            km.p = kmin(km.p, kp);
-            km.n = kmin(km.n, kn);
+            offer_m(km, kp, kn);
         });
-        km.tp = km.p != om.p ? tprev_id : om.tp;
-        km.tn = km.n != om.n ? tprev_id : om.tn;
+        settle_tiles_m(km, om, tprev_id);
     }
 }
 
@@ -582,16 +624,8 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
     };
     if (!MATCHED) {
         // this lane's two candidates and the partner lane's, best two of the four by (key, index)
-        const uint32_t k1 = key_row(ku.b1, ku.t1, h), k2 = key_row(ku.b2, ku.t2, h);
-        const uint32_t pb1 = xor32(ku.b1), pb2 = xor32(ku.b2), pk1 = xor32(k1), pk2 = xor32(k2);
         uint32_t f, fi, sd, si;
-        if (keyless(pb1, pk1, ku.b1, k1)) {
-            f = pb1; fi = pk1;
-            if (keyless(ku.b1, k1, pb2, pk2)) { sd = ku.b1; si = k1; } else { sd = pb2; si = pk2; }
-        } else {
-            f = ku.b1; fi = k1;
-            if (keyless(pb1, pk1, ku.b2, k2)) { sd = pb1; si = pk1; } else { sd = ku.b2; si = k2; }
-        }
+        merge_pair(ku.b1, ku.t1, ku.b2, ku.t2, h, f, fi, sd, si);
         if (key_valid(f) && !unsafe) {
             const float d1 = dist(fi);
             wp.d = d1; wp.i = fi;
@@ -611,18 +645,28 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
             unsafe = true;
         }
     } else {
-        uint32_t kp = key_row(km.p, km.tp, h), kn = key_row(km.n, km.tn, h), p = km.p, n = km.n;
-        const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
-        if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
-        if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
-        if (key_valid(p)) {
-            wp.d = dist(kp); wp.i = kp;
-            unsafe |= !(wp.d < INFINITY);
-        }
-        if (key_valid(n)) {
-            wn.d = dist(kn); wn.i = kn;
-            unsafe |= !(wn.d < INFINITY);
-        }
+        // each class group like the unlabelled search: best two of the pair's four, the runner-up re-measured
+        // where its key is within the margin of the winner's (decided per wave)
+        auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, Best1 &w) {
+            uint32_t f, fi, sd, si;
+            merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
+            const bool have = key_valid(f);
+            float d1 = INFINITY;
+            if (have) {
+                d1 = dist(fi);
+                w.d = d1; w.i = fi;
+            }
+            const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
+            if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+                if (have && key_valid(sd)) {
+                    const float d2 = dist(si);
+                    if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
+                }
+            }
+            if (have) unsafe |= !(w.d < INFINITY);
+        };
+        group(km.p, km.tp, km.p2, km.tp2, wp);
+        group(km.n, km.tn, km.n2, km.tn2, wn);
     }
     if (unsafe) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
         wp = Best1();
