@@ -197,11 +197,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                         const uint32_t key = pack_key(acc[t][o], o);
                         const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;     // helpers.rs:113 / :122
                         const uint32_t kp = match ? key : KEY_NONE, kn = match ? KEY_NONE : key;
-                        km.p = kmin(km.p, kp);
-                        km.n = kmin(km.n, kn);
+                        offer_m(km, kp, kn);
                     });
-                    km.tp = km.p != before.p ? tile : before.tp;
-                    km.tn = km.n != before.n ? tile : before.tn;
+                    settle_tiles_m(km, before, tile);
                 }
             });
             }
@@ -211,27 +209,22 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
             // ---- the lane pair agrees on two candidates; pass 2 re-measures them
             uint32_t c0, c1;                           // unlabelled: best two; labelled: best matching, best non-matching
             bool v0, v1;
+            uint32_t r0 = 0u, r1 = 0u;                 // labelled: the two groups' runner-ups, where their keys are close
+            bool w0 = false, w1 = false;
             if (!MATCHED) {
-                const uint32_t k1 = key_row(ku.b1, ku.t1, h), k2 = key_row(ku.b2, ku.t2, h);
-                const uint32_t pb1 = xor32(ku.b1), pb2 = xor32(ku.b2), pk1 = xor32(k1), pk2 = xor32(k2);
                 uint32_t f, sd;
-                if (keyless(pb1, pk1, ku.b1, k1)) {
-                    f = pb1; c0 = pk1;
-                    if (keyless(ku.b1, k1, pb2, pk2)) { sd = ku.b1; c1 = k1; } else { sd = pb2; c1 = pk2; }
-                } else {
-                    f = ku.b1; c0 = k1;
-                    if (keyless(pb1, pk1, ku.b2, k2)) { sd = pb1; c1 = pk1; } else { sd = ku.b2; c1 = k2; }
-                }
+                merge_pair(ku.b1, ku.t1, ku.b2, ku.t2, h, f, c0, sd, c1);
                 v0 = key_valid(f);
                 v1 = key_valid(sd);
             } else {
-                uint32_t kp = key_row(km.p, km.tp, h), kn = key_row(km.n, km.tn, h), p = km.p, n = km.n;
-                const uint32_t pp = xor32(p), pkp = xor32(kp), pn = xor32(n), pkn = xor32(kn);
-                if (keyless(pp, pkp, p, kp)) { p = pp; kp = pkp; }
-                if (keyless(pn, pkn, n, kn)) { n = pn; kn = pkn; }
-                c0 = kp; c1 = kn;
-                v0 = key_valid(p);
-                v1 = key_valid(n);
+                const float margin = (fmaf(ss, 1.00390625f, 1e-30f) + a.wmax2) * 6.103515625e-05f;
+                uint32_t fp, sp, fn, sn;
+                merge_pair(km.p, km.tp, km.p2, km.tp2, h, fp, c0, sp, r0);
+                merge_pair(km.n, km.tn, km.n2, km.tn2, h, fn, c1, sn, r1);
+                v0 = key_valid(fp);
+                v1 = key_valid(fn);
+                w0 = v0 && key_valid(sp) && !(__builtin_bit_cast(float, sp) - __builtin_bit_cast(float, fp) > margin);
+                w1 = v1 && key_valid(sn) && !(__builtin_bit_cast(float, sn) - __builtin_bit_cast(float, fn) > margin);
             }
             float e0, e1;
             exact_pair(b, v0 ? c0 : 0u, v1 ? c1 : 0u, e0, e1);
@@ -249,8 +242,22 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                     unsafe = true;
                 }
             } else {
-                if (v0) { wp.d = sqrtf(e0); wp.i = c0; unsafe |= !(wp.d < INFINITY); }
-                if (v1) { wn.d = sqrtf(e1); wn.i = c1; unsafe |= !(wn.d < INFINITY); }
+                if (v0) { wp.d = sqrtf(e0); wp.i = c0; }
+                if (v1) { wn.d = sqrtf(e1); wn.i = c1; }
+                if (__builtin_amdgcn_ballot_w64(w0 || w1) != 0ull) {      // a runner-up within the margin somewhere in the wave
+                    float e2, e3;
+                    exact_pair(b, w0 ? r0 : 0u, w1 ? r1 : 0u, e2, e3);
+                    if (w0) {
+                        const float d2 = sqrtf(e2);
+                        if (lexless(d2, r0, wp.d, wp.i)) { wp.d = d2; wp.i = r0; }
+                    }
+                    if (w1) {
+                        const float d3 = sqrtf(e3);
+                        if (lexless(d3, r1, wn.d, wn.i)) { wn.d = d3; wn.i = r1; }
+                    }
+                }
+                if (v0) unsafe |= !(wp.d < INFINITY);
+                if (v1) unsafe |= !(wn.d < INFINITY);
             }
             if (__builtin_amdgcn_ballot_w64(unsafe) != 0ull) {
                 // exact scan in index order (helpers.rs:55-77 in f32), two prototypes per sweep over the rows; the
