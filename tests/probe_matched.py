@@ -1,7 +1,8 @@
-"""Scratch probe: hard mismatches of the matched search on low-dimensional data (python tools/matched_probe.py D K N)."""
+"""Probe (not collected by pytest; part of the test infrastructure, it uses the oracle): mismatches of the plain and
+the labelled search against the oracle on uniform data of a given shape.  python tests/probe_matched.py D K N"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from vq_amd import Context
 import parity
