@@ -823,6 +823,47 @@ def test_euclid_and_local_dispatch_grids(ctx):
     assert {"mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local", "mfma_local_long"} <= seen, seen
 
 
+def test_matched_dispatch_grid(ctx):
+    """The labelled search (rows a4 / a6) under VQHIP_KERNEL_AUTO against the scalar kernels on the device, over shapes
+    of all three model kinds: both winners of every sample, every kernel family."""
+    rng = np.random.default_rng(11)
+    N, kernels = 300, set()
+    cases = [(D, K, 0, "none") for D in (3, 16, 64, 100, 128, 200, 256, 300, 784) for K in (1, 2, 5, 33, 257, 1000)]
+    cases += [(D, K, M, "global") for D in (32, 100, 128, 200, 256, 300) for M in (2, 16, 40, 128, 200) for K in (3, 40, 300)]
+    cases += [(D, K, M, "local") for D in (16, 128, 200, 300) for M in (1, 33) for K in (2, 20)]
+    for D, K, M, kind in cases:
+        W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+        X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+        cls = (np.arange(K) % 3).astype(np.uint32)
+        y = rng.integers(0, 3, size=N).astype(np.uint32)
+        shape = (M, D) if kind == "global" else (K, M, D)
+        Om = None if kind == "none" else (rng.uniform(-1, 1, size=shape) / np.sqrt(M * D / 3.0)).astype(np.float32)
+        out = {}
+        for policy in (KERNEL_SCALAR, KERNEL_AUTO):
+            ctx.set_kernel_policy(policy)
+            ctx.set_prototypes(W)
+            if kind == "global":
+                ctx.set_omega(Om)
+            elif kind == "local":
+                ctx.set_local_omegas(Om)
+            ctx.set_labels(cls)
+            out[policy] = ctx.assign_matched(X, y) + (ctx.last_kernel,)
+        s, a = out[KERNEL_SCALAR], out[KERNEL_AUTO]
+        # hundreds of prototypes in a plane or a thousand in space: some triple lies closer together than the f32
+        # screening resolves, and the library keeps such a model on the scalar kernels (DESIGN.md section 2)
+        dense = (kind == "global" and M <= 2 and K >= 300) or (kind == "none" and D <= 3 and K >= 1000)
+        assert s[4] == "scalar" and (a[4].startswith("mfma_") or (dense and a[4] == "scalar")), ((D, K, M, kind), s[4], a[4])
+        kernels.add(a[4])
+        for si, sd, ai, ad in ((s[0], s[1], a[0], a[1]), (s[2], s[3], a[2], a[3])):
+            sd, ad = sd.astype(np.float64), ad.astype(np.float64)
+            fin = np.isfinite(sd)
+            assert (np.isfinite(ad) == fin).all(), (D, K, M, kind, a[4])          # no eligible prototype: +INF on both
+            assert np.all(np.abs(ad[fin] - sd[fin]) <= 1e-4 * np.abs(sd[fin]) + 2e-6), (D, K, M, kind, a[4])
+            assert (si == ai).mean() > 0.97, (D, K, M, kind, a[4])
+    ctx.set_kernel_policy(KERNEL_AUTO)
+    assert len(kernels) >= 12, kernels
+
+
 @pytest.mark.parametrize("case", [(5000, 128, 32), (3001, 64, 64), (2500, 64, 7), (1999, 32, 50)], ids=lambda c: "n%d_d%d_k%d" % c)
 def test_staged_kernel(ctx, case):
     """Few prototypes: rows staged through LDS by 1 KiB LDS-DMA pieces (2 / 4 / 8 rows per piece at D = 128 / 64 / 32).
