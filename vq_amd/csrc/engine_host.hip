@@ -422,7 +422,9 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
         }
         {
             const double gap = second_neighbour_gap(Q, K, L);
-            if (gap >= 0.0 && gap < 1.6e-5 * 2.0 * std::max(wmax2, 1e-300) && !getenv("VQHIP_DENSE_OK")) {
+            // too many prototypes for the pairwise pass: in up to 3 dimensions that many of them ARE dense
+            const bool unchecked_low_dim = gap < 0.0 && K >= 3 && L <= 3;
+            if (((gap >= 0.0 && gap < 1.6e-5 * 2.0 * std::max(wmax2, 1e-300)) || unchecked_low_dim) && !getenv("VQHIP_DENSE_OK")) {
                 why = "three or more prototypes closer to each other than the f32 screening resolves";
                 return nullptr;
             }
