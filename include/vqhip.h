@@ -109,6 +109,25 @@ int vqhip_assign_rows_f64(vqhip_ctx *ctx, const double *const *rows, uint64_t N,
 int vqhip_assign_device(vqhip_ctx *ctx, const float *dX, uint64_t N, uint32_t *didx_out,
                         float *ddist_out, void *stream);
 
+/* Builds the device images of the model now instead of inside the first assign call after a vqhip_set_*
+ * (they are device allocations + uploads).  No counterpart in the reference: its model lives in host Vecs. */
+int vqhip_prepare(vqhip_ctx *ctx);
+
+/* vqhip_assign_device for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has NO counterpart in the reference; results are those of
+ * vqhip_assign_device bit for bit.  It calls no hipMalloc / hipFree / allocating routine: the only device memory the
+ * kernels need beyond inputs and outputs -- the batch counters they claim work from, 64 KiB -- lives in a
+ * file-scope __device__ array of the library, one copy per GPU for the life of the process.
+ *   - the model must be prepared (vqhip_prepare, or any assign call since the last vqhip_set_*): VQHIP_ERR_STATE otherwise
+ *   - it serves the models one MFMA kernel serves (what vqhip_last_kernel reports as mfma_* except
+ *     mfma_omega_two_pass); for the others VQHIP_ERR_UNSUPPORTED (their scratch grows with N)
+ *   - N <= VQHIP_NOALLOC_MAX_ROWS, VQHIP_ERR_INVALID beyond (the counters are 32-bit)
+ *   - every call on one GPU shares that GPU's counters: calls that overlap on one GPU (two streams, two contexts,
+ *     two threads) race.  Order them on one stream or use vqhip_assign_device. */
+#define VQHIP_NOALLOC_MAX_ROWS (1ull << 36)
+int vqhip_assign_device_noalloc(vqhip_ctx *ctx, const float *dX, uint64_t N, uint32_t *didx_out,
+                                float *ddist_out, void *stream);
+
 /* find_closest_prototype_matched, both calls of the fit loop at once (src/helpers.rs:91-132 as
  * called at src/glvq/glvq.rs:171-176; local: src/lgmlvq/lgmlvq.rs:468-506 as called at :194-199).
  * y[i] = class id of sample i.  jpos/dpos: nearest prototype with cls == y[i];

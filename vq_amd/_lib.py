@@ -31,6 +31,8 @@ SIGNATURES = {
     "vqhip_assign_matched_f64": (C.c_int, [_v, C.POINTER(C.c_double), _u, C.c_uint64, _u, C.POINTER(C.c_double), _u,
                                            C.POINTER(C.c_double)]),
     "vqhip_assign_device": (C.c_int, [_v, _v, C.c_uint64, _v, _v, _v]),
+    "vqhip_prepare": (C.c_int, [_v]),
+    "vqhip_assign_device_noalloc": (C.c_int, [_v, _v, C.c_uint64, _v, _v, _v]),
     "vqhip_assign_matched": (C.c_int, [_v, _f, _u, C.c_uint64, _u, _f, _u, _f]),
     "vqhip_assign_matched_device": (C.c_int, [_v, _v, _v, C.c_uint64, _v, _v, _v, _v, _v]),
     "vqhip_last_kernel": (C.c_char_p, [_v]),

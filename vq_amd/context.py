@@ -184,6 +184,10 @@ class Context:
 
         self._check_torch(X)
         N = X.shape[0]
+        self._check_outputs(N, idx_out, dist_out, jneg_out, dneg_out)
+        if y is not None and not (y.is_cuda and y.device == X.device and y.dtype == torch.int32 and y.is_contiguous()
+                                  and tuple(y.shape) == (N,)):
+            raise ValueError("y must be a contiguous CUDA int32 tensor with one class id per sample")
         stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
 
         def p(t):
@@ -194,6 +198,21 @@ class Context:
         else:
             self._chk(self._L.vqhip_assign_matched_device(self._h, p(X), p(y), N, p(idx_out), p(dist_out),
                                                           p(jneg_out), p(dneg_out), stream))
+
+    def prepare(self):
+        """Builds the model's device images now (vqhip_prepare)."""
+        self._chk(self._L.vqhip_prepare(self._h))
+
+    def assign_into_noalloc(self, X, idx_out, dist_out=None, n=None):
+        """vqhip_assign_device_noalloc: the device path that allocates nothing (the model must be prepared)."""
+        import torch
+
+        self._check_torch(X)
+        N = X.shape[0] if n is None else int(n)
+        self._check_outputs(N if n is None else 0, idx_out, dist_out)
+        stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+        self._chk(self._L.vqhip_assign_device_noalloc(self._h, C.c_void_p(X.data_ptr()), N, C.c_void_p(idx_out.data_ptr()),
+                                                      C.c_void_p(dist_out.data_ptr()) if dist_out is not None else None, stream))
 
     def project_into(self, X, Y_out, which: int = _lib.PROJECT_LAMBDA):
         """Device path of project / project_omega: X and Y_out are torch tensors on the GPU (N x D -> N x D or N x M)."""
@@ -223,6 +242,21 @@ class Context:
         dn = torch.empty(N, dtype=torch.float32, device=X.device)
         self.assign_into(X, idx, dist, y, jn, dn)
         return idx, dist, jn, dn
+
+    def _check_outputs(self, N, idx_out, dist_out=None, jneg_out=None, dneg_out=None):
+        """Output tensors are written by the kernels through raw pointers: N elements, 4 bytes each, contiguous,
+        on the context's GPU."""
+        import torch
+
+        for t, dt, name in ((idx_out, torch.int32, "idx_out"), (dist_out, torch.float32, "dist_out"),
+                            (jneg_out, torch.int32, "jneg_out"), (dneg_out, torch.float32, "dneg_out")):
+            if t is None:
+                if name == "idx_out":
+                    raise ValueError("idx_out is required")
+                continue
+            if not (t.is_cuda and t.device.index == self.device and t.dtype == dt and t.is_contiguous() and t.numel() >= N
+                    and t.dim() == 1):
+                raise ValueError(f"{name} must be a contiguous 1-D CUDA {dt} tensor on cuda:{self.device} with at least {N} elements")
 
     def _check_shape(self, shape):
         if len(shape) != 2 or shape[1] != self.D:

@@ -6,15 +6,46 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 
+#include "mfma_host.h"
 #include "vq_common.h"
 
 using namespace vq;
 
+// ---- batch counters of vqhip_assign_device_noalloc (include/vqhip.h) ----------------------------------------------
+// The kernels claim their batches from QUEUE_GROUPS counters in device memory (BlockQueue, mfma_device.h), which every
+// launch zeroes first.  The other entry points take them from the model's own hipMalloc'ed slots; the entry point
+// that may not allocate takes them from this array.  Every GPU the library runs on holds its own copy (64 KiB) at its
+// own address until the process ends.  In host code the NAME below is only a handle for hipGetSymbolAddress: what a
+// kernel or hipMemsetAsync gets is the per-device address looked up once in noalloc_scratch_setup().
+static __device__ __align__(256) uint32_t scratch[QUEUE_BYTES / sizeof(uint32_t)];
+
 namespace {
 thread_local std::string g_create_error;
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+uint32_t *g_scratch_ptr[MAX_DEVICES] = {};      // device address of `scratch` per GPU, null until looked up
+
+// With `device` current: the address of this GPU's copy of `scratch`, looked up once per device and process.
+hipError_t noalloc_scratch_setup(int device, uint32_t **out)
+{
+    *out = nullptr;
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (uint32_t *)p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 struct Staging {                 // one of the two halves of the host-path pipeline
     hipStream_t stream = nullptr;
@@ -49,6 +80,8 @@ struct vqhip_ctx {
     // The scratch buffers are shared by every stream the context is driven from (the host path alternates
     // two): the last kernel that uses one records this event, the next user waits for it on its stream.
     hipEvent_t scratch_done = nullptr;
+
+    uint32_t *noalloc_queue = nullptr;   // this GPU's copy of `scratch` (device address, set in vqhip_create)
 
     EngineModel *engine = nullptr;
     // A global Omega no single-pass kernel holds (more than 128 rows over rows above 256 values; more than 64 rows
@@ -615,6 +648,12 @@ int vqhip_create(int device, vqhip_ctx **out)
         return VQHIP_ERR_NOMEM;
     }
     c->device = device;
+    // the device is current: look up this GPU's copy of the no-allocation entry point's counters
+    if ((e = noalloc_scratch_setup(device, &c->noalloc_queue)) != hipSuccess) {
+        g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+        delete c;
+        return VQHIP_ERR_HIP;
+    }
     *out = c;
     return VQHIP_OK;
 }
@@ -766,6 +805,37 @@ int vqhip_assign_device(vqhip_ctx *c, const float *dX, uint64_t N, uint32_t *did
     if (N && (!dX || !didx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_device: dX or didx_out is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_device(c, dX, N, nullptr, Outputs{didx_out, ddist_out, nullptr, nullptr}, (hipStream_t)stream);
+}
+
+int vqhip_prepare(vqhip_ctx *c)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
+    HIPCHK(c, hipSetDevice(c->device));
+    return prepare_engine(c);
+}
+
+int vqhip_assign_device_noalloc(vqhip_ctx *c, const float *dX, uint64_t N, uint32_t *didx_out, float *ddist_out, void *stream)
+{
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N > VQHIP_NOALLOC_MAX_ROWS)
+        return c->fail(VQHIP_ERR_INVALID, "assign_device_noalloc: N exceeds VQHIP_NOALLOC_MAX_ROWS (2^36 rows; the batch counters are 32-bit)");
+    if (N && (!dX || !didx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_device_noalloc: dX or didx_out is NULL");
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
+    // the tile images are device memory: they must exist already (vqhip_prepare, or any assign call since the last vqhip_set_*)
+    if (!c->engine_tried || c->policy == VQHIP_KERNEL_SCALAR)
+        return c->fail(VQHIP_ERR_STATE, "assign_device_noalloc: model not prepared (call vqhip_prepare after the last vqhip_set_*; not with VQHIP_KERNEL_SCALAR)");
+    if (!c->engine)
+        return c->fail(VQHIP_ERR_UNSUPPORTED, "assign_device_noalloc serves the models one MFMA kernel serves; this one needs scratch "
+                                              "proportional to N (use vqhip_assign_device): " + c->engine_why);
+    if (!c->noalloc_queue) return c->fail(VQHIP_ERR_STATE, "assign_device_noalloc: the counters of this GPU were not set up");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (N == 0) return VQHIP_OK;
+    c->last_kernel = engine_name(c->engine);
+    // c->noalloc_queue is the device address of `scratch` on this GPU (never the array's name); the launch zeroes it
+    HIPCHK(c, engine_assign(c->engine, dX, N, nullptr, Outputs{didx_out, ddist_out, nullptr, nullptr}, (hipStream_t)stream,
+                            c->noalloc_queue));
+    return VQHIP_OK;
 }
 
 int vqhip_assign_matched(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, uint32_t *jpos, float *dpos,

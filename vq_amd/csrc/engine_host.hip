@@ -510,7 +510,7 @@ void engine_free(EngineModel *m)
 
 const char *engine_name(const EngineModel *m) { return m->name; }
 
-hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s)
+hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s, uint32_t *queue)
 {
     if (N == 0) return hipSuccess;
     EngineArgs a;
@@ -526,11 +526,11 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.wmax2 = m->wmax2;
     a.dbg = nullptr;
     static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
-    if (variant_env() == 31) {
+    if (variant_env() == 31 && !queue) {
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
-    a.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
+    a.queue = queue ? queue : m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
     a.dup_first = m->dup_first;
     a.dup_next = m->dup_next;
     a.cls = m->cls;

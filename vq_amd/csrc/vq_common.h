@@ -71,8 +71,10 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                           hipError_t &herr);
 void engine_free(EngineModel *m);
 const char *engine_name(const EngineModel *m);
+// queue: batch counters to use instead of the model's own slots (QUEUE_BYTES of device memory; the launch zeroes
+// them), or null
 hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out,
-                         hipStream_t s);
+                         hipStream_t s, uint32_t *queue = nullptr);
 
 // Y = X . A^T on the matrix cores for an A (rows x D) resident in LDS; nullptr when D is not 32/64/128/256.
 struct ProjectModel;
