@@ -24,6 +24,7 @@ class ParityReport:
     hard: int                # ... of which it is not (failures)
     max_rel_err: float
     dist_fail: int
+    floor_used: int = 0      # distances beyond rtol that pass only through the absolute floor `atol`
 
     @property
     def ok(self) -> bool:
@@ -31,7 +32,7 @@ class ParityReport:
 
     def __str__(self):
         return (f"n={self.n} mismatches={self.mismatches} near_ties={self.near_ties} hard={self.hard} "
-                f"max_rel_err={self.max_rel_err:.3g} dist_fail={self.dist_fail}")
+                f"max_rel_err={self.max_rel_err:.3g} dist_fail={self.dist_fail} floor_used={self.floor_used}")
 
 
 def compare(idx, dist, o_idx, o_best, o_second, rtol=DIST_RTOL, atol=0.0, tau=TIE_TAU) -> ParityReport:
@@ -45,7 +46,7 @@ def compare(idx, dist, o_idx, o_best, o_second, rtol=DIST_RTOL, atol=0.0, tau=TI
         gap = (o_second - o_best) / np.maximum(o_best, np.finfo(np.float64).tiny)
     near = mism & np.isfinite(gap) & (gap < tau)
     hard = mism & ~near
-    max_rel, dist_fail = 0.0, 0
+    max_rel, dist_fail, floor_used = 0.0, 0, 0
     if dist is not None:
         d = np.asarray(dist, dtype=np.float64)
         want = np.where(mism, o_second, o_best)           # a tolerated mismatch picked the runner-up
@@ -56,8 +57,9 @@ def compare(idx, dist, o_idx, o_best, o_second, rtol=DIST_RTOL, atol=0.0, tau=TI
         bad = err > rtol * np.abs(want[fin]) + atol
         bad &= ~hard[fin]                                  # do not double count hard index failures
         dist_fail += int(bad.sum())
+        floor_used = int(((err > rtol * np.abs(want[fin])) & ~bad & ~hard[fin]).sum()) if atol else 0
         with np.errstate(invalid="ignore", divide="ignore"):
             rel = err / np.maximum(np.abs(want[fin]), max(atol, 1e-300) if atol else 1e-300)
         rel = rel[np.abs(want[fin]) > atol] if atol else rel[np.abs(want[fin]) > 0]
         max_rel = float(rel.max()) if rel.size else 0.0
-    return ParityReport(n, int(mism.sum()), int(near.sum()), int(hard.sum()), max_rel, dist_fail)
+    return ParityReport(n, int(mism.sum()), int(near.sum()), int(hard.sum()), max_rel, dist_fail, floor_used)

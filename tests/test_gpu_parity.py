@@ -755,9 +755,8 @@ def test_global_omega_dispatch_grid(ctx):
                     out[policy] = (idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64), ctx.last_kernel)
                 si, sd, sk = out[KERNEL_SCALAR]
                 ai, ad, ak = out[KERNEL_AUTO]
-                # dozens of prototypes projected onto a line: some triple lies closer together than the f32 screening resolves (scalar by design)
-                dense = M == 1 and K >= 40
-                assert sk == "scalar" and (ak.startswith("mfma_omega") or (dense and ak == "scalar")), (D, M, K, sk, ak)
+                # (dozens of prototypes projected onto a line included: crowded samples take the kernels' exact scan)
+                assert sk == "scalar" and ak.startswith("mfma_omega"), (D, M, K, sk, ak)
                 seen.add(ak)
                 # distances first: a different winner within tolerance shows up as a near-equal distance
                 assert np.all(np.abs(ad - sd) <= 1e-4 * np.abs(sd) + 2e-6), (D, M, K, ak, float(np.abs(ad - sd).max()))
@@ -767,10 +766,8 @@ def test_global_omega_dispatch_grid(ctx):
     assert {"mfma_omega_lds", "mfma_omega_lowrank_lds", "mfma_omega", "mfma_omega_long", "mfma_omega_two_pass"} <= seen, seen
 
 
-def _auto_vs_scalar(ctx, Xd, N, load, what, prefix, rtol=1e-4, atol=2e-6, dense_ok=False):
-    """One model under both policies on the device; returns the AUTO kernel's name.  dense_ok: the model may be one
-    the library keeps on the scalar kernels because its prototypes lie closer to each other than the f32 screening
-    resolves (engine_host.hip second_neighbour_gap)."""
+def _auto_vs_scalar(ctx, Xd, N, load, what, prefix, rtol=1e-4, atol=2e-6):
+    """One model under both policies on the device; returns the AUTO kernel's name."""
     import torch
     out = {}
     for policy in (KERNEL_SCALAR, KERNEL_AUTO):
@@ -783,7 +780,7 @@ def _auto_vs_scalar(ctx, Xd, N, load, what, prefix, rtol=1e-4, atol=2e-6, dense_
         out[policy] = (idx.cpu().numpy(), dist.cpu().numpy().astype(np.float64), ctx.last_kernel)
     si, sd, sk = out[KERNEL_SCALAR]
     ai, ad, ak = out[KERNEL_AUTO]
-    assert sk == "scalar" and (ak.startswith(prefix) or (dense_ok and ak == "scalar")), (what, sk, ak)
+    assert sk == "scalar" and ak.startswith(prefix), (what, sk, ak)
     assert np.all(np.abs(ad - sd) <= rtol * np.abs(sd) + atol), (what, ak, float(np.abs(ad - sd).max()))
     assert (ai == si).mean() > 0.97, (what, ak, float((ai == si).mean()))
     return ak
@@ -801,11 +798,8 @@ def test_euclid_and_local_dispatch_grids(ctx):
         Xd = torch.from_numpy(X).cuda()
         for K in (1, 2, 33, 256, 257, 1000, 5000):
             W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
-            # hundreds of random prototypes on a line or in space: some triple lies within 1e-3 of each other
-            dense = (D == 1 and K >= 256) or (D == 3 and K >= 1000)
-            ak = _auto_vs_scalar(ctx, Xd, N, lambda: ctx.set_prototypes(W), (D, K), "mfma_euclid", rtol=1e-5, atol=1e-7, dense_ok=dense)
-            if D == 1 and K == 5000:
-                assert ak == "scalar"                                  # 5000 prototypes in [-1, 1): 4e-4 apart
+            # (thousands of random prototypes on a line included: crowded samples take the kernels' exact scan)
+            ak = _auto_vs_scalar(ctx, Xd, N, lambda: ctx.set_prototypes(W), (D, K), "mfma_euclid", rtol=1e-5, atol=1e-7)
             seen.add(ak)
     for D in (16, 100, 128, 200, 256, 300, 400):
         X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
@@ -849,10 +843,7 @@ def test_matched_dispatch_grid(ctx):
             ctx.set_labels(cls)
             out[policy] = ctx.assign_matched(X, y) + (ctx.last_kernel,)
         s, a = out[KERNEL_SCALAR], out[KERNEL_AUTO]
-        # hundreds of prototypes in a plane or a thousand in space: some triple lies closer together than the f32
-        # screening resolves, and the library keeps such a model on the scalar kernels
-        dense = (kind == "global" and M <= 2 and K >= 300) or (kind == "none" and D <= 3 and K >= 1000)
-        assert s[4] == "scalar" and (a[4].startswith("mfma_") or (dense and a[4] == "scalar")), ((D, K, M, kind), s[4], a[4])
+        assert s[4] == "scalar" and a[4].startswith("mfma_"), ((D, K, M, kind), s[4], a[4])
         kernels.add(a[4])
         for si, sd, ai, ad in ((s[0], s[1], a[0], a[1]), (s[2], s[3], a[2], a[3])):
             sd, ad = sd.astype(np.float64), ad.astype(np.float64)

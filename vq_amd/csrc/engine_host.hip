@@ -24,12 +24,12 @@ struct EngineModel {
     // one still running would hand its batches to it.  Slots are used round-robin.
     uint32_t *queue = nullptr;
     mutable uint32_t next_slot = 0;
-    uint32_t *dup_first = nullptr, *dup_next = nullptr;     // identical search-space rows (null: none)
+    float *mu = nullptr;                                    // centre subtracted from every sample (R1 floats), null: none
     uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
     const char *name = "mfma";
     LaunchFn launch = nullptr;
     int samples_per_batch = 0;
-    float ss_limit = 0.0f, wmax2 = 0.0f;
+    float ss_limit = 0.0f, wmax2 = 0.0f, mscale = 6.103515625e-05f;
 };
 
 namespace {
@@ -44,9 +44,13 @@ int pad_pow2(uint32_t v, int lo)
     return r;
 }
 
-// Groups of prototypes with identical rows (-0 counted as +0): first / next tables for settle_ties, left
-// empty when every row is unique.
-void find_duplicates(const std::vector<float> &Q, uint32_t K, uint32_t L, std::vector<uint32_t> &first, std::vector<uint32_t> &next)
+// Prototypes whose search-space row repeats that of an earlier prototype (-0 counted as +0) of the same class (any
+// earlier one when the model has no classes): their distances equal the earlier one's bit for bit, so under strict '<'
+// in index order (helpers.rs:70, :113, :122) they never win a search the earlier one is eligible for -- and it is
+// eligible for every search they are.  They are left out of the SCREENING (their score column is PAD_SCORE; the exact
+// scan still walks them), so a model with many copies of a prototype does not look crowded to the third-key guard
+// (finish_keys, mfma_device.h).
+std::vector<bool> shadowed_rows(const std::vector<float> &Q, uint32_t K, uint32_t L, const std::vector<uint32_t> &cls)
 {
     std::vector<float> canon(Q.begin(), Q.begin() + (size_t)K * L);
     for (float &v : canon) v += 0.0f;
@@ -57,57 +61,56 @@ void find_duplicates(const std::vector<float> &Q, uint32_t K, uint32_t L, std::v
         const int c = row_cmp(x, y);
         return c < 0 || (c == 0 && x < y);
     });
-    bool any = false;
-    std::vector<uint32_t> f(K), n(K);
+    std::vector<bool> drop(K, false);
     for (uint32_t i = 0; i < K;) {
         uint32_t j = i + 1;
         while (j < K && row_cmp(order[i], order[j]) == 0) ++j;
-        for (uint32_t t = i; t < j; ++t) {
-            f[order[t]] = order[i];
-            n[order[t]] = t + 1 < j ? order[t + 1] : order[t];
-        }
-        any |= j - i > 1;
+        for (uint32_t t = i + 1; t < j; ++t)             // order[i..j) ascending by index
+            for (uint32_t e = i; e < t && !drop[order[t]]; ++e)
+                drop[order[t]] = cls.empty() || cls[order[e]] == cls[order[t]];
         i = j;
     }
-    if (any) {
-        first = std::move(f);
-        next = std::move(n);
-    }
+    return drop;
 }
 
-// Screening works on scores ||w||^2 - 2 x.w in f32 (error about 2e-6 of the norm scale once the keys' 4 mantissa
-// bits are dropped) and re-measures the best TWO candidates in the direct form.  A sample next to three or more
-// prototypes that lie closer to each other than that error can have its true winner outside the two: such models
-// are left to the scalar kernels (direct form throughout).  Returns the smallest squared distance from a prototype
-// to its second-nearest distinct neighbour, or -1 when the pairwise pass would be too long for the host (then the
-// model is taken as it is).
-double second_neighbour_gap(const std::vector<float> &Q, uint32_t K, uint32_t L)
+// The centre the kernels subtract from every sample before anything else: the mean prototype, when the prototypes
+// sit off the origin by more than their own spread.  The screening error scales with ||x||^2 + max ||w||^2, the
+// distances do not: for data around (100, 100, ...) with unit spread the uncentred keys would resolve nothing.
+// x - mu is one f32 subtraction per value (exact by Sterbenz's lemma exactly where it matters, x and mu within a
+// factor of two of each other, and for coarse-grained data: mu is rounded to 8 significant bits); the prototypes are shifted by the same f32 operation here, so a sample that equals a
+// prototype bit for bit still has distance 0.  Everything downstream (images, norms, projections, the exact
+// re-measurement) lives in the shifted coordinates.  Returns false (mu left empty) when the shift would not halve the
+// mean squared norm.
+bool centre_prototypes(const std::vector<float> &W, uint32_t K, uint32_t D, std::vector<float> &mu, std::vector<float> &Wc)
 {
-    if (K < 3 || (double)K * K * L > 4e8) return -1.0;
-    const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    std::vector<double> best(nthreads, INFINITY);
-    std::vector<std::thread> pool;
-    for (unsigned w = 0; w < nthreads; ++w)
-        pool.emplace_back([&, w] {
-            for (uint32_t i = w; i < K; i += nthreads) {
-                double q1 = INFINITY, q2 = INFINITY;
-                const float *a = &Q[(size_t)i * L];
-                for (uint32_t j = 0; j < K; ++j) {
-                    if (j == i) continue;
-                    const float *b = &Q[(size_t)j * L];
-                    double t = 0.0;
-                    for (uint32_t d = 0; d < L && t < q2; ++d) {
-                        const double df = (double)a[d] - (double)b[d];
-                        t += df * df;
-                    }
-                    if (!(t > 0.0)) continue;                      // identical rows tie bit for bit: settle_ties
-                    if (t < q1) { q2 = q1; q1 = t; } else if (t < q2) q2 = t;
-                }
-                if (q2 < best[w]) best[w] = q2;
-            }
-        });
-    for (std::thread &t : pool) t.join();
-    return *std::min_element(best.begin(), best.end());
+    if (getenv("VQHIP_NO_CENTRE")) return false;
+    std::vector<double> mean(D, 0.0);
+    double sumsq = 0.0;
+    for (uint32_t k = 0; k < K; ++k)
+        for (uint32_t d = 0; d < D; ++d) {
+            const double v = W[(size_t)k * D + d];
+            mean[d] += v;
+            sumsq += v * v;
+        }
+    double mu2 = 0.0;
+    std::vector<float> m(D);
+    for (uint32_t d = 0; d < D; ++d) {
+        // 8 significant bits: x - mu is then EXACT for integer, binary and other coarse-grained data as well (the shift
+        // changes nothing there, exact ties stay exact ties), and where x and mu are within a factor of two anyway
+        int ex = 0;
+        const double fr = std::frexp(mean[d] / K, &ex);
+        m[d] = (float)std::ldexp(std::nearbyint(std::ldexp(fr, 8)), ex - 8);
+        mu2 += (double)m[d] * (double)m[d];
+    }
+    if (!(mu2 * K > 0.5 * sumsq) || !std::isfinite(mu2)) return false;   // also false for NaN / INF prototypes
+    mu = std::move(m);
+    Wc.resize((size_t)K * D);
+    for (uint32_t k = 0; k < K; ++k)
+        for (uint32_t d = 0; d < D; ++d) {
+            volatile float t = W[(size_t)k * D + d] - mu[d];             // one f32 subtraction, as on the device
+            Wc[(size_t)k * D + d] = t;
+        }
+    return true;
 }
 
 int variant_env()
@@ -370,7 +373,7 @@ bool bind_local(EngineModel &m, std::vector<float> &img, const std::vector<float
 
 }  // namespace
 
-EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, const std::vector<float> &Om,
+EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D, const std::vector<float> &Om,
                           int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, std::string &why,
                           hipError_t &herr)
 {
@@ -390,8 +393,13 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
     m.R1 = D > 256 ? 0u : (uint32_t)pad_pow2(D, 16);
     m.has_cls = !cls.empty();
     std::vector<float> img1, img2, plain;
-    std::vector<uint32_t> dup_first, dup_next;
     bool ok = false;
+
+    // the coordinates everything below lives in: the caller's, or shifted by the mean prototype (centre_prototypes).
+    // Rows above 256 values keep the caller's coordinates (the long-row kernels fetch their rows in chunks, twice).
+    std::vector<float> mu, Wc;
+    const bool centred = D <= 256 && centre_prototypes(Win, K, D, mu, Wc);
+    const std::vector<float> &W = centred ? Wc : Win;
 
     if (omega_kind == OMEGA_NONE || omega_kind == OMEGA_GLOBAL) {
         // search space: the prototypes themselves, or their projections p_k = Omega w_k (f64, rounded once)
@@ -420,46 +428,45 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
                 return nullptr;
             }
         }
+        // screening scores: ||q_k||^2, or PAD_SCORE for rows that repeat an earlier row of their class
+        std::vector<float> scores = norms;
         {
-            const double gap = second_neighbour_gap(Q, K, L);
-            // too many prototypes for the pairwise pass: in up to 3 dimensions that many of them ARE dense
-            const bool unchecked_low_dim = gap < 0.0 && K >= 3 && L <= 3;
-            if (((gap >= 0.0 && gap < 1.6e-5 * 2.0 * std::max(wmax2, 1e-300)) || unchecked_low_dim) && !getenv("VQHIP_DENSE_OK")) {
-                why = "three or more prototypes closer to each other than the f32 screening resolves";
-                return nullptr;
-            }
+            const std::vector<bool> drop = shadowed_rows(Q, K, L, cls);
+            for (uint32_t k = 0; k < K; ++k)
+                if (drop[k]) scores[k] = PAD_SCORE;
         }
         // ||x||^2 below this: |2 x.w| <= 2 sqrt(ss wmax2) <= 1e18 and ||w||^2 + c stay far inside f32 range
         m.ss_limit = (float)std::min(1e36, 1e36 / (4.0 * std::max(wmax2, 1e-36)));
         m.wmax2 = (float)wmax2;
+        // screen_margin (mfma_device.h): twice the error of one key, reduction length L
+        m.mscale = (float)std::max(6.103515625e-05, 4.0 * (8.0 * std::sqrt((double)L) * 5.9604644775390625e-08 + 1.9073486328125e-06));
         if (omega_kind == OMEGA_NONE) {
             m.mode = MODE_EUCLID;
             m.name = "mfma_euclid";
             m.ldp = m.R1;
-            ok = bind_long(m, img1, img2, W, norms, cls) || bind_euclid<16>(m, img1, W, norms, cls) || bind_euclid<32>(m, img1, W, norms, cls) ||
-                 bind_euclid<64>(m, img1, W, norms, cls) || bind_euclid<128>(m, img1, W, norms, cls) ||
-                 bind_euclid<256>(m, img1, W, norms, cls);
+            ok = bind_long(m, img1, img2, W, scores, cls) || bind_euclid<16>(m, img1, W, scores, cls) || bind_euclid<32>(m, img1, W, scores, cls) ||
+                 bind_euclid<64>(m, img1, W, scores, cls) || bind_euclid<128>(m, img1, W, scores, cls) ||
+                 bind_euclid<256>(m, img1, W, scores, cls);
         } else {
             m.mode = MODE_OMEGA;
             m.name = "mfma_omega";
             m.R2 = (uint32_t)pad_pow2(M, 16);
             m.ldp = m.R2;
-            ok = bind_omega_long<32>(m, img1, img2, Om, P, norms, cls) || bind_omega_long<64>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega_long<128>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_lowrank<256>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<128>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_lowrank<64>(m, img1, img2, Om, P, norms, cls) || bind_lowrank<32>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega_pipe<128>(m, img1, img2, Om, P, norms, cls) || bind_omega_pipe<64>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega_pipe<32>(m, img1, img2, Om, P, norms, cls) ||
+            ok = bind_omega_long<32>(m, img1, img2, Om, P, scores, cls) || bind_omega_long<64>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_omega_long<128>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_lowrank<256>(m, img1, img2, Om, P, scores, cls) || bind_lowrank<128>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_lowrank<64>(m, img1, img2, Om, P, scores, cls) || bind_lowrank<32>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_omega_pipe<128>(m, img1, img2, Om, P, scores, cls) || bind_omega_pipe<64>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_omega_pipe<32>(m, img1, img2, Om, P, scores, cls) ||
                  // streamed engine: per R1 the narrowest instantiated search width that holds Omega's rows
-                 bind_omega<16, 16>(m, img1, img2, Om, P, norms, cls) || bind_omega<32, 16>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega<32, 32>(m, img1, img2, Om, P, norms, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega<128, 128>(m, img1, img2, Om, P, norms, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, norms, cls) ||
-                 bind_omega<256, 64>(m, img1, img2, Om, P, norms, cls);
+                 bind_omega<16, 16>(m, img1, img2, Om, P, scores, cls) || bind_omega<32, 16>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_omega<32, 32>(m, img1, img2, Om, P, scores, cls) || bind_omega<64, 64>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_omega<128, 128>(m, img1, img2, Om, P, scores, cls) || bind_omega<256, 16>(m, img1, img2, Om, P, scores, cls) ||
+                 bind_omega<256, 64>(m, img1, img2, Om, P, scores, cls);
         }
         // zero-padded plain rows for the exact re-measurement
         plain.assign((size_t)K * m.ldp, 0.0f);
         for (uint32_t k = 0; k < K; ++k) std::memcpy(&plain[(size_t)k * m.ldp], &Q[(size_t)k * L], L * sizeof(float));
-        find_duplicates(Q, K, L, dup_first, dup_next);
     } else {
         m.mode = MODE_LOCAL;
         m.name = "mfma_local";
@@ -485,8 +492,10 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
     if (herr == hipSuccess && !img2.empty()) herr = to_device(&out->img2, img2);
     if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
     if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
-    if (herr == hipSuccess && !dup_first.empty()) herr = to_device(&out->dup_first, dup_first);
-    if (herr == hipSuccess && !dup_next.empty()) herr = to_device(&out->dup_next, dup_next);
+    if (herr == hipSuccess && centred) {
+        mu.resize(256, 0.0f);                                          // zero padded to the longest fragment a kernel reads
+        herr = to_device(&out->mu, mu);
+    }
     if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, QUEUE_SLOTS * QUEUE_STRIDE * sizeof(uint32_t));
     if (herr != hipSuccess) {
         engine_free(out);
@@ -503,8 +512,7 @@ void engine_free(EngineModel *m)
     (void)hipFree(m->plain);
     (void)hipFree(m->cls);
     (void)hipFree(m->queue);
-    (void)hipFree(m->dup_first);
-    (void)hipFree(m->dup_next);
+    (void)hipFree(m->mu);
     delete m;
 }
 
@@ -531,8 +539,8 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
         a.dbg = dbg_buf;
     }
     a.queue = queue ? queue : m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
-    a.dup_first = m->dup_first;
-    a.dup_next = m->dup_next;
+    a.mu = m->mu;
+    a.mscale = m->mscale;
     a.cls = m->cls;
     hipError_t e = m->launch(a, dy != nullptr, s);
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch

@@ -43,6 +43,8 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
     constexpr int NG1 = (T1 + G1::G - 1) / G1::G;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
     __shared__ uint32_t claimed;                                     // the batch after this one
+    __shared__ __attribute__((aligned(16))) float mu_lds[R1];
+    stage_centre<R1>(mu_lds, a.mu, threadIdx.x, 256);                // published by the first barrier below
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s_col = lane & 31, h = lane >> 5;
@@ -119,6 +121,10 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         __syncthreads();
         const uint64_t bnext = claimed;
         mask_columns();
+        if (a.mu != nullptr) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) centre_fragment<R1 / 8, 2>(xf[s], mu_lds, h);
+        }
         uint64_t sample[S];
         uint32_t lab[S];
 #pragma unroll
@@ -131,11 +137,12 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         Keys2 ku[S];
         KeysM km[S];
         Best1 pos[S], neg[S];                                         // LOCAL: exact distances, offered in index order
-        float dsum[S];
+        float dsum[S], margin[S];
         bool unsafe[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             dsum[s] = 0.0f;
+            margin[s] = 0.0f;
             unsafe[s] = false;
         }
         if (MODE != MODE_OMEGA) {
@@ -204,6 +211,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     for (int e = 0; e < 4; ++e) ss = fmaf(yf[s][j][e], yf[s][j][e], ss);
                 ss += xor32(ss);
                 unsafe[s] = !(ss < a.ss_limit);
+                margin[s] = screen_margin(ss, a);
             }
         }
 
@@ -295,40 +303,32 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     const float d = exact_sq<RS>(yf[s], a.plain, a.ldp, k, h);
                     return ROOT ? sqrtf(d) : d;
                 };
-                if (!MATCHED) {
-                    uint32_t f, fi, sd, si;                            // best two of the pair's four, by (key, index)
-                    merge_pair(ku[s].b1, ku[s].t1, ku[s].b2, ku[s].t2, h, f, fi, sd, si);
-                    if (key_valid(f) && !rescan) {
+                // each group: best two of the pair's four by (key, index), both re-measured; a third key within the
+                // margin of the best sends the sample to the exact scan (the guarantee: finish_keys, mfma_device.h)
+                const bool skip = rescan;
+                auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w) {
+                    uint32_t f, fi, sd, si;
+                    merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
+                    const float third = pair_third(b1, b2, b3);
+                    const bool have = key_valid(f) && !skip;
+                    if (have) {
                         const float d1 = measure(fi);
-                        wp.d = d1; wp.i = fi;
+                        w.d = d1; w.i = fi;
                         if (key_valid(sd)) {
                             const float d2 = measure(si);
-                            if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+                            if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
                         }
-                        rescan = !(wp.d < INFINITY);
-                    } else {
-                        rescan = true;
+                        rescan |= !(third - __builtin_bit_cast(float, f) > margin[s]) || !(w.d < INFINITY);
                     }
+                    return have;
+                };
+                if (!MATCHED) {
+                    if (!group(ku[s].b1, ku[s].t1, ku[s].b2, ku[s].t2, ku[s].b3, wp)) rescan = true;
                 } else {
-                    // each class group like the unlabelled search: best two of the pair's four, both re-measured
-                    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, Best1 &w) {
-                        uint32_t f, fi, sd, si;
-                        merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
-                        if (key_valid(f)) {
-                            const float d1 = measure(fi);
-                            w.d = d1; w.i = fi;
-                            if (key_valid(sd)) {
-                                const float d2 = measure(si);
-                                if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
-                            }
-                            rescan |= !(w.d < INFINITY);
-                        }
-                    };
-                    group(km[s].p, km[s].tp, km[s].p2, km[s].tp2, wp);
-                    group(km[s].n, km[s].tn, km[s].n2, km[s].tn2, wn);
+                    group(km[s].p, km[s].tp, km[s].p2, km[s].tp2, km[s].p3, wp);
+                    group(km[s].n, km[s].tn, km[s].n2, km[s].tn2, km[s].n3, wn);
                 }
                 if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn);
-                settle_ties<MATCHED>(a, lab[s], wp, wn);
             }
             if (live) {
                 if (h == 0) {

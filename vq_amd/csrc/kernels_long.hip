@@ -211,13 +211,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
             bool v0, v1;
             uint32_t r0 = 0u, r1 = 0u;                 // labelled: the two groups' runner-ups, where their keys are close
             bool w0 = false, w1 = false;
+            // a third key within the margin of a group's best: the exact scan below (the guarantee: finish_keys, mfma_device.h)
+            const float margin = screen_margin(ss, a);
             if (!MATCHED) {
                 uint32_t f, sd;
                 merge_pair(ku.b1, ku.t1, ku.b2, ku.t2, h, f, c0, sd, c1);
                 v0 = key_valid(f);
                 v1 = key_valid(sd);
+                if (v0) unsafe |= !(pair_third(ku.b1, ku.b2, ku.b3) - __builtin_bit_cast(float, f) > margin);
             } else {
-                const float margin = (fmaf(ss, 1.00390625f, 1e-30f) + a.wmax2) * 6.103515625e-05f;
                 uint32_t fp, sp, fn, sn;
                 merge_pair(km.p, km.tp, km.p2, km.tp2, h, fp, c0, sp, r0);
                 merge_pair(km.n, km.tn, km.n2, km.tn2, h, fn, c1, sn, r1);
@@ -225,6 +227,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                 v1 = key_valid(fn);
                 w0 = v0 && key_valid(sp) && !(__builtin_bit_cast(float, sp) - __builtin_bit_cast(float, fp) > margin);
                 w1 = v1 && key_valid(sn) && !(__builtin_bit_cast(float, sn) - __builtin_bit_cast(float, fn) > margin);
+                if (v0) unsafe |= !(pair_third(km.p, km.p2, km.p3) - __builtin_bit_cast(float, fp) > margin);
+                if (v1) unsafe |= !(pair_third(km.n, km.n2, km.n3) - __builtin_bit_cast(float, fn) > margin);
             }
             float e0, e1;
             exact_pair(b, v0 ? c0 : 0u, v1 ? c1 : 0u, e0, e1);
@@ -275,7 +279,6 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                 }
                 if (unsafe) { wp = sp; wn = sn; }
             }
-            settle_ties<MATCHED>(a, label, wp, wn);
             {
                 const int rec = (int)rows.records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;
@@ -407,14 +410,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
                 for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
             ss += xor32(ss);
             const bool unsafe = !(ss < a.ss_limit);
-            const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+            const float margin = unsafe ? 0.0f : screen_margin(ss, a);
 
             Keys2 ku;
             KeysM km;
             search_tiles<R2, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
             Best1 wp, wn;
-            finish_keys<R2, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
-            settle_ties<MATCHED>(a, label, wp, wn);
+            finish_keys<R2, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
             {
                 const int rec = (int)rows.records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;

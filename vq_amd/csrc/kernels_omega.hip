@@ -29,13 +29,16 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
     constexpr int ROWF = R1 + 4;                       // Omega row stride in LDS: rows start 4 banks apart
     constexpr int NJ = R1 / 16;                        // projection steps: 4 MFMAs per step and sample group
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    __shared__ __attribute__((aligned(16))) float mu_lds[R1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const int n16 = lane & 15, kg = lane >> 4;
     const uint32_t ntiles = a.res_tiles;
     const uint32_t p_bytes = ntiles * Gs::TILE_BYTES;
+    const bool centred = a.mu != nullptr;
 
     {   // both images -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        stage_centre<R1>(mu_lds, a.mu, threadIdx.x, NW * 64);
         auto to_lds = [&](uint32_t dst, const char *src, uint32_t bytes) {
             for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
                 const uint32_t off = p * 1024u + lane * 16u;
@@ -111,6 +114,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
                 xn[1][j] = mask_chunk(xn[1][j], (uint32_t)(4 * j + kg), a.D);
             }
         }
+        if (centred) {                                 // entry j of both groups holds chunk 4 j + kg of its row
+            centre_fragment<NJ, 4>(xn[0], mu_lds, kg);
+            centre_fragment<NJ, 4>(xn[1], mu_lds, kg);
+        }
         {
             f32x4 anext = *(const f32x4 *)om;
             static_for<0, NJ>([&](auto jj) {
@@ -155,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
             for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
         ss += xor32(ss);                               // ||y||^2, the same value in both lanes of the pair
         const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge: exact scan at the end
-        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+        const float margin = unsafe ? 0.0f : screen_margin(ss, a);
 
         // ---- search in the projected space (k_resident_pipe's tile loop at R = 16)
         Keys2 ku;
@@ -163,8 +170,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         search_tiles<16, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
 
         Best1 wp, wn;
-        finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
-        settle_ties<MATCHED>(a, label, wp, wn);
+        finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
         {
             const int rec = (int)records(b, 4u);
             const uint32_t so = (uint32_t)s_col * 4u;
@@ -201,11 +207,14 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     constexpr int NT = R / 32, NJ = R / 8, NSTEP = NT * NJ;   // Omega tiles, reduction steps per tile, pieces
     constexpr int DEPTH = 6;                                  // Omega pieces in flight per wave
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    __shared__ __attribute__((aligned(16))) float mu_lds[R];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const uint32_t ntiles = a.res_tiles;
+    const bool centred = a.mu != nullptr;
 
     {   // prototype image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        stage_centre<R>(mu_lds, a.mu, threadIdx.x, NW * 64);
         const uint32_t bytes = ntiles * Gs::TILE_BYTES;
         const char *src = (const char *)a.img2;
         for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
@@ -278,6 +287,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
 #pragma unroll
             for (int j = 0; j < R / 8; ++j) xn[j] = mask_chunk(xn[j], (uint32_t)(2 * j + h), a.D);
         }
+        if (centred) centre_fragment<R / 8, 2>(xn, mu_lds, h);
         {
             f32x4 ring[DEPTH];
 #pragma unroll
@@ -312,7 +322,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
             for (int e = 0; e < 4; ++e) ss = fmaf(yf[j][e], yf[j][e], ss);
         ss += xor32(ss);                               // ||y||^2, the same value in both lanes of the pair
         const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge: exact scan at the end
-        const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+        const float margin = unsafe ? 0.0f : screen_margin(ss, a);
 
         // ---- search in the projected space (k_resident_pipe's tile loop)
         Keys2 ku;
@@ -320,8 +330,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
 
         Best1 wp, wn;
-        finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
-        settle_ties<MATCHED>(a, label, wp, wn);
+        finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
         {
             const int rec = (int)records(b, 4u);
             const uint32_t so = (uint32_t)s_col * 4u;

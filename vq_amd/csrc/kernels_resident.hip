@@ -13,6 +13,7 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 {
     using Gm = Geom<R>;
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    __shared__ __attribute__((aligned(16))) float mu_lds[R];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const uint32_t ntiles = a.res_tiles;
@@ -20,6 +21,7 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
 
     {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        stage_centre<R>(mu_lds, a.mu, threadIdx.x, 512);
         const uint32_t bytes = ntiles * Gm::TILE_BYTES;
         const char *src = (const char *)a.img1;
         for (uint32_t p = wave; p * 1024u < bytes; p += 8) {
@@ -53,14 +55,14 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
             for (int j = 0; j < R / 8; ++j)
                 xf[s][j] = mask_chunk(__builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0)),
                                       (uint32_t)(2 * j + h), a.D);
+            if (a.mu != nullptr) centre_fragment<R / 8, 2>(xf[s], mu_lds, h);
             label[s] = 0u;
             if (MATCHED) {
                 const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + first), 0, (int)rec_y, 0x00020000);
                 label[s] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
             }
         }
-        Top2 top[S];
-        Best1 pos[S], neg[S];
+        Top2 top[S], neg[S];                                          // labelled: top = matching group, neg = the other
 
         for (uint32_t t = 0; t < ntiles; ++t) {
             const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
@@ -78,8 +80,7 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         const float v = acc[s][4 * g + e];
-                        if (!MATCHED) top[s].offer(v, k);
-                        else if (cg[e] == label[s]) pos[s].offer(v, k);           // helpers.rs:113
+                        if (!MATCHED || cg[e] == label[s]) top[s].offer(v, k);     // helpers.rs:113
                         else neg[s].offer(v, k);                                   // helpers.rs:122
                     }
                 }
@@ -90,31 +91,32 @@ __global__ void __launch_bounds__(512, 2) k_resident(const EngineArgs a)
         for (int s = 0; s < S; ++s) {
             const bool live = sample[s] < a.N;
             Best1 wp, wn;
-            bool rescan = false;
-            if (!MATCHED) {
-                top[s].merge_halves();
-                const Top2 &t = top[s];
-                if (t.b1 < KEY_VALID_F) {
+            float ss = 0.0f;
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ss = fmaf(xf[s][j][e], xf[s][j][e], ss);
+            ss += xor32(ss);
+            bool rescan = !(ss < a.ss_limit);                          // NaN / INF / huge rows: their scores mean nothing
+            const float margin = screen_margin(ss, a);
+            // the group's best two scores re-measured exactly; a third score within the margin of the best: exact scan
+            // (the guarantee: finish_keys, mfma_device.h)
+            auto settle = [&](Top2 &t, Best1 &w) {
+                t.merge_halves();
+                if (t.b1 < KEY_VALID_F && !rescan) {
                     const float d1 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i1, h));
-                    wp.d = d1; wp.i = t.i1;
+                    w.d = d1; w.i = t.i1;
                     if (t.b2 < KEY_VALID_F) {
                         const float d2 = sqrtf(exact_sq_lds<R>(xf[s], img, t.i2, h));
-                        if (lexless(d2, t.i2, d1, t.i1)) { wp.d = d2; wp.i = t.i2; }
+                        if (lexless(d2, t.i2, d1, t.i1)) { w.d = d2; w.i = t.i2; }
                     }
-                    rescan = t.b1 == -INFINITY || !(wp.d < INFINITY);
+                    return !(t.b3 - t.b1 > margin) || !(w.d < INFINITY);
                 }
-            } else {
-                pos[s].merge_halves();
-                neg[s].merge_halves();
-                if (pos[s].d < KEY_VALID_F) {
-                    wp.d = sqrtf(exact_sq_lds<R>(xf[s], img, pos[s].i, h)); wp.i = pos[s].i;
-                    rescan |= pos[s].d == -INFINITY || !(wp.d < INFINITY);
-                }
-                if (neg[s].d < KEY_VALID_F) {
-                    wn.d = sqrtf(exact_sq_lds<R>(xf[s], img, neg[s].i, h)); wn.i = neg[s].i;
-                    rescan |= neg[s].d == -INFINITY || !(wn.d < INFINITY);
-                }
-            }
+                return false;
+            };
+            const bool crowded_p = settle(top[s], wp);
+            const bool crowded_n = MATCHED ? settle(neg[s], wn) : false;
+            rescan |= crowded_p || crowded_n;
             if (rescan) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
                 wp = Best1();
                 wn = Best1();
@@ -174,12 +176,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         }
     };
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
+    __shared__ __attribute__((aligned(16))) float mu_lds[R];
     const unsigned long long r_entry = DIAG ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const uint32_t ntiles = a.res_tiles;
+    const bool centred = a.mu != nullptr;
 
     {   // whole image -> LDS, linear LDS-DMA, 1 KiB per wave-instruction
+        stage_centre<R>(mu_lds, a.mu, threadIdx.x, NW * 64);
         const uint32_t bytes = ntiles * Gm::TILE_BYTES;
         const char *src = (const char *)a.img1;
         for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
@@ -276,6 +281,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 for (int j = 0; j < R / 8; ++j) xf[j] = *(const f32x4 *)(rowp + 32 * j);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            if (centred) centre_fragment<R / 8, 2>(xf, mu_lds, h);
 #pragma unroll
             for (int j = 0; j < R / 8; ++j) {
                 const f32x2 lo = {xf[j][0], xf[j][1]}, hi = {xf[j][2], xf[j][3]};
@@ -286,7 +292,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             float ss = ss2[0] + ss2[1];
             ss += xor32(ss);                           // ||x||^2, the same value in both lanes of the pair
             const bool unsafe = !(ss < a.ss_limit);    // NaN / INF / huge rows: exact scan at the end
-            const float c = unsafe ? 0.0f : fmaf(ss, 1.00390625f, 1e-30f);
+            const float margin = unsafe ? 0.0f : screen_margin(ss, a);
             lap(0);                                    // 0: delivery of this batch's rows
             // vmcnt counts in issue order: the atomic goes out only after this batch's rows have been waited
             // for, or that wait would include the atomic's own round trip
@@ -302,8 +308,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             lap(2);                                    // 2: tile loop
 
             Best1 wp, wn;
-            finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, (c + a.wmax2) * 6.103515625e-05f, ku, km, wp, wn);
-            settle_ties<MATCHED>(a, label, wp, wn);
+            finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
             {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
                 const int rec = (int)records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;

@@ -33,12 +33,11 @@ struct EngineArgs {
     uint32_t res_tiles;       // resident kernels: tiles of 32 prototypes actually searched, ceil(K / 32)
     uint64_t nbatches;
     Outputs out;
-    float wmax2;              // largest ||w_k||^2 (screening error bound)
+    float wmax2;              // largest ||w_k||^2 (screening error bound), in the centred coordinates when mu is set
+    float mscale;             // screening margin = mscale * (||x||^2 + wmax2): see screen_margin
+    const float *mu;          // centre subtracted from every sample before anything else (R1 floats, zero padded), or null
     float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
-    // Prototypes whose search-space rows are identical (null when the model has none): dup_first[k] = lowest
-    // index with k's row, dup_next[k] = next higher index with it.  See settle_ties.
-    const uint32_t *dup_first, *dup_next;
     const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
 };
@@ -75,12 +74,13 @@ __device__ __forceinline__ void static_for(F &&f)
 // Running best two (value, index) of a lane.  Offers arrive with increasing index, so strict '<'
 // keeps the lower index on ties (helpers.rs:70); NaN never enters.
 struct Top2 {
-    float b1, b2;
+    float b1, b2, b3;                                   // b3: third best value (the crowding guard, see finish_keys)
     uint32_t i1, i2;
-    __device__ Top2() : b1(INFINITY), b2(INFINITY), i1(0u), i2(0u) {}
+    __device__ Top2() : b1(INFINITY), b2(INFINITY), b3(INFINITY), i1(0u), i2(0u) {}
     __device__ __forceinline__ void offer(float v, uint32_t k)
     {
         const bool c1 = v < b1, c2 = v < b2;
+        b3 = c2 ? b2 : (v < b3 ? v : b3);
         b2 = c1 ? b1 : (c2 ? v : b2);
         i2 = c1 ? i1 : (c2 ? k : i2);
         b1 = c1 ? v : b1;
@@ -89,8 +89,10 @@ struct Top2 {
     // union with the partner lane's pair (the other 16 rows of every tile)
     __device__ __forceinline__ void merge_halves()
     {
-        const float o1 = xor32(b1), o2 = xor32(b2);
+        const float o1 = xor32(b1), o2 = xor32(b2), o3 = xor32(b3);
         const uint32_t oi1 = xor32(i1), oi2 = xor32(i2);
+        // third smallest of the two sorted triples
+        b3 = fminf(fminf(b3, o3), fminf(fmaxf(b1, o2), fmaxf(b2, o1)));
         float f, s;
         uint32_t fi, si;
         if (lexless(o1, oi1, b1, i1)) {
@@ -121,24 +123,6 @@ struct Best1 {
         if (lexless(o, oi, d, i)) { d = o; i = oi; }
     }
 };
-
-// Exact ties between identical prototypes.  The packed keys order equal scores by position inside the
-// tile before tile number, and keep only two (labelled searches: one) candidates, so among three
-// identical rows the one found need not be the first.  Identical rows have bit-identical distances, so
-// the winner is moved to the first ELIGIBLE prototype with its row (helpers.rs:70: strict '<' keeps the
-// first; helpers.rs:113 / :122: eligibility).  Costs one null test per batch for models without duplicates.
-template <bool MATCHED>
-__device__ __forceinline__ void settle_ties(const EngineArgs &a, uint32_t label, Best1 &wp, Best1 &wn)
-{
-    if (a.dup_first == nullptr) return;
-    auto lowest = [&](uint32_t k, bool want_match) {
-        uint32_t i = a.dup_first[k];
-        while (i != k && MATCHED && (a.cls[i] == label) != want_match) i = a.dup_next[i];
-        return i;
-    };
-    if (wp.d < INFINITY) wp.i = lowest(wp.i, true);
-    if (MATCHED && wn.d < INFINITY) wn.i = lowest(wn.i, false);
-}
 
 // ------------------------------------------------------------------------------ batch queue of the wave-per-batch kernels
 // Every wave works through blocks of BLOCK consecutive batches of 32 samples.  Its first block is fixed (its
@@ -198,12 +182,16 @@ struct BlockQueue {
 // sent to the exact scan anyway.
 constexpr uint32_t KEY_NONE = 0x7F800000u;           // +INF: "no candidate yet"
 constexpr float KEY_VALID_F = 1.0e38f;               // keys of real prototypes are below this
-struct Keys2 {                       // unlabelled search: best two keys and their tiles
+// The THIRD best key (value only) is the crowding guard: the two best are re-measured exactly, and that settles the
+// sample only if no other prototype's key lies within the screening error of the best one (finish_keys).
+struct Keys2 {                       // unlabelled search: best two keys and their tiles, third best key
     uint32_t b1 = KEY_NONE, b2 = KEY_NONE, t1 = 0u, t2 = 0u;
+    uint32_t b3 = KEY_NONE;
 };
-struct KeysM {                       // labelled search: best two keys with cls == y, best two with cls != y, their tiles
+struct KeysM {                       // labelled search: best two keys with cls == y, best two with cls != y, their tiles; third best keys
     uint32_t p = KEY_NONE, n = KEY_NONE, tp = 0u, tn = 0u;
     uint32_t p2 = KEY_NONE, n2 = KEY_NONE, tp2 = 0u, tn2 = 0u;
+    uint32_t p3 = KEY_NONE, n3 = KEY_NONE;
 };
 __device__ __forceinline__ bool key_valid(uint32_t key) { return __builtin_bit_cast(float, key) < KEY_VALID_F; }
 
@@ -229,13 +217,15 @@ __device__ __forceinline__ uint32_t kmed3(uint32_t x, uint32_t y, uint32_t z)   
 // KEY_NONE), kn the other way round; each group keeps its best two (the runner-up is re-measured where it is close).
 __device__ __forceinline__ void offer_m(KeysM &km, uint32_t kp, uint32_t kn)
 {
+    km.p3 = kmed3(km.p2, km.p3, kp);
     km.p2 = kmed3(km.p, km.p2, kp);
     km.p = kmin(km.p, kp);
+    km.n3 = kmed3(km.n2, km.n3, kn);
     km.n2 = kmed3(km.n, km.n2, kn);
     km.n = kmin(km.n, kn);
 }
 // The 16 scores of one finished tile offered to the lane's best two keys: position bits in, median, minimum
-// (3 VALU per score).  One asm statement: the compiler pads a wait state behind every inline-asm result
+// and the third best key (4 VALU per score).  One asm statement: the compiler pads a wait state behind every inline-asm result
 // that the next instruction reads, and the chain b1 -> b1 would collect one per score.  PRE_NOPS: wait
 // states for accumulators that the MFMA right in front of the statement has written.
 template <int PRE_NOPS = 0>
@@ -246,53 +236,69 @@ __device__ __forceinline__ void screen16(const f32x16 &sc, Keys2 &ku)
     asm(
         "v_and_or_b32 %[t0], %[s0], %[m], 0\n\t"
         "v_and_or_b32 %[t1], %[s1], %[m], 1\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
         "v_and_or_b32 %[t0], %[s2], %[m], 2\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
         "v_and_or_b32 %[t1], %[s3], %[m], 3\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
         "v_and_or_b32 %[t0], %[s4], %[m], 4\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
         "v_and_or_b32 %[t1], %[s5], %[m], 5\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
         "v_and_or_b32 %[t0], %[s6], %[m], 6\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
         "v_and_or_b32 %[t1], %[s7], %[m], 7\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
         "v_and_or_b32 %[t0], %[s8], %[m], 8\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
         "v_and_or_b32 %[t1], %[s9], %[m], 9\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
         "v_and_or_b32 %[t0], %[s10], %[m], 10\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
         "v_and_or_b32 %[t1], %[s11], %[m], 11\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
         "v_and_or_b32 %[t0], %[s12], %[m], 12\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
         "v_and_or_b32 %[t1], %[s13], %[m], 13\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
         "v_and_or_b32 %[t0], %[s14], %[m], 14\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
         "v_and_or_b32 %[t1], %[s15], %[m], 15\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
         "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
         "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
         "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [b3] "+v"(ku.b3), [t0] "=&v"(t0), [t1] "=&v"(t1)
         : [s0] "v"(sc[0]), [s1] "v"(sc[1]), [s2] "v"(sc[2]), [s3] "v"(sc[3]), [s4] "v"(sc[4]), [s5] "v"(sc[5]), [s6] "v"(sc[6]), [s7] "v"(sc[7]), [s8] "v"(sc[8]), [s9] "v"(sc[9]), [s10] "v"(sc[10]), [s11] "v"(sc[11]), [s12] "v"(sc[12]), [s13] "v"(sc[13]), [s14] "v"(sc[14]), [s15] "v"(sc[15]), [m] "s"(0xFFFFFFF0u));
 }
 // After a tile's scores went in: which tile do the best two keys come from now
@@ -348,6 +354,24 @@ __device__ __forceinline__ void merge_pair(uint32_t b1, uint32_t t1, uint32_t b2
     }
 }
 
+// Third smallest key of the lane pair's two sorted triples (value only; +INF while fewer than three were offered)
+__device__ __forceinline__ float pair_third(uint32_t b1, uint32_t b2, uint32_t b3)
+{
+    const float a1 = __builtin_bit_cast(float, b1), a2 = __builtin_bit_cast(float, b2), a3 = __builtin_bit_cast(float, b3);
+    const float c1 = xor32(a1), c2 = xor32(a2), c3 = xor32(a3);
+    return fminf(fminf(a3, c3), fminf(fmaxf(a1, c2), fmaxf(a2, c1)));
+}
+
+// How far two screening keys may lie apart while the order of the true scores ||w||^2 - 2 x.w is still open:
+// twice the error of one key, which is the f32 accumulation of the fma chain (bounded by gamma_L * (||w||^2 +
+// 2 ||w|| ||x||) <= gamma_L * (2 wmax2 + ss)) plus the 4 mantissa bits the position replaces (2^-19 of the same).
+// mscale (host, engine_build) = max(2^-14, 4 (8 sqrt(L) 2^-24 + 2^-19)) for a reduction of length L: above the
+// worst-case bound up to L = 200, a many-sigma bound on the accumulated rounding beyond.
+__device__ __forceinline__ float screen_margin(float ss, const EngineArgs &a)
+{
+    return (fmaf(ss, 1.00390625f, 1e-30f) + a.wmax2) * a.mscale;
+}
+
 // Chunk c = 2j + h of a row of D floats fetched as 16 bytes: values at or past D belong to the next row (or are
 // range-check zeros).  The weight images are zero there, but 0 x INF is NaN, so they are cleared.  D need not
 // be a multiple of 4 (rows are then only 4-byte aligned, which buffer loads accept).
@@ -356,6 +380,25 @@ __device__ __forceinline__ f32x4 mask_chunk(f32x4 v, uint32_t c, uint32_t D)
     const uint32_t first = 4u * c;
     if (first + 4u <= D) return v;
     return f32x4{first + 0u < D ? v[0] : 0.f, first + 1u < D ? v[1] : 0.f, first + 2u < D ? v[2] : 0.f, 0.f};
+}
+
+// Centre of the model (EngineArgs::mu) -> LDS at kernel start, NF floats; the caller's barrier publishes it.
+template <int NF>
+__device__ __forceinline__ void stage_centre(float *mu_lds, const float *mu, int tid, int nthreads)
+{
+    if (mu != nullptr)
+        for (int i = tid; i < NF; i += nthreads) mu_lds[i] = mu[i];
+}
+// x -= mu for a fragment whose entry j holds chunk j * CSTEP + c0 of the row (engine.h: CSTEP = 2, c0 = h).  One
+// v_sub per value: the prototypes were shifted by the same f32 operation on the host (centre_prototypes).
+template <int NJ, int CSTEP>
+__device__ __forceinline__ void centre_fragment(f32x4 (&xf)[NJ], const float *mu_lds, int c0)
+{
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const f32x4 m = *(const f32x4 *)(mu_lds + 4 * (j * CSTEP + c0));
+        xf[j] = xf[j] - m;
+    }
 }
 
 // LDS-DMA of one stage (BYTES, multiple of 16) from its pre-swizzled global image: a linear copy,
@@ -612,6 +655,14 @@ __device__ __forceinline__ void search_tiles(const float *img, uint32_t ntiles, 
 
 // Final step of a batch: the lane pair agrees on the candidates, re-measures them in the direct
 // (x - w)^2 form from the LDS image, roots, compares like helpers.rs:70.
+//
+// The guarantee.  Screening orders the prototypes by keys that differ from the true scores ||w||^2 - 2 x.w by less
+// than margin / 2 each (screen_margin).  The best TWO keys are re-measured exactly, so the answer is the reference's
+// as long as every other prototype's key lies more than `margin` above the best key -- none of them can then be
+// closer than the best candidate.  The third best key says whether that holds: where it does not (three or more
+// prototypes closer to each other, seen from this sample, than the f32 screening resolves: dense models, exact
+// multi-way ties, duplicates) the sample takes the exact in-order scan below, which IS helpers.rs:55-77 / 91-132 in
+// f32 (strict '<' in index order, so the lowest index wins ties).
 template <int R, bool MATCHED, bool ROOT = true>
 __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h,
                                             bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
@@ -622,51 +673,36 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         const float d = exact_sq_lds<R>(xf, img, k, h);
         return ROOT ? sqrtf(d) : d;
     };
-    if (!MATCHED) {
-        // this lane's two candidates and the partner lane's, best two of the four by (key, index)
+    // best two of the pair's four by (key, index), re-measured; the runner-up only where its key is within the margin
+    // of the winner's (decided per wave: the re-measurement is 80 VALU + 16 LDS reads for every lane or for none)
+    const bool skip = unsafe;                          // NaN / INF / huge rows: their keys mean nothing
+    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w) {
         uint32_t f, fi, sd, si;
-        merge_pair(ku.b1, ku.t1, ku.b2, ku.t2, h, f, fi, sd, si);
-        if (key_valid(f) && !unsafe) {
-            const float d1 = dist(fi);
-            wp.d = d1; wp.i = fi;
-            // The runner-up is re-measured only where it can still win: a key differs from the true
-            // ||w||^2 - 2 x.w by less than margin/2 (f32 accumulation of 2 x.w, rounding of the
-            // init column, the 4 truncated bits), so a gap above `margin` decides the order already.
-            // Decided per wave: the re-measurement is 80 VALU + 16 LDS reads for every lane or for none.
-            const bool close = key_valid(sd) && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
-            if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
-                if (key_valid(sd)) {
-                    const float d2 = dist(si);
-                    if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
-                }
-            }
-            unsafe = !(wp.d < INFINITY);
-        } else {
-            unsafe = true;
+        merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
+        const float third = pair_third(b1, b2, b3);
+        const bool have = key_valid(f) && !skip;
+        const float fk = __builtin_bit_cast(float, f);
+        float d1 = INFINITY;
+        if (have) {
+            d1 = dist(fi);
+            w.d = d1; w.i = fi;
         }
+        const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - fk > margin);
+        if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+            if (have && key_valid(sd)) {
+                const float d2 = dist(si);
+                if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
+            }
+        }
+        // crowded: a third key within the margin; a non-finite re-measured winner cannot be trusted either
+        if (have) unsafe |= !(third - fk > margin) || !(w.d < INFINITY);
+        return have;
+    };
+    if (!MATCHED) {
+        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp)) unsafe = true;      // no usable key at all: the scan answers (0, +INF)
     } else {
-        // each class group like the unlabelled search: best two of the pair's four, the runner-up re-measured
-        // where its key is within the margin of the winner's (decided per wave)
-        auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, Best1 &w) {
-            uint32_t f, fi, sd, si;
-            merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
-            const bool have = key_valid(f);
-            float d1 = INFINITY;
-            if (have) {
-                d1 = dist(fi);
-                w.d = d1; w.i = fi;
-            }
-            const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - __builtin_bit_cast(float, f) > margin);
-            if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
-                if (have && key_valid(sd)) {
-                    const float d2 = dist(si);
-                    if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
-                }
-            }
-            if (have) unsafe |= !(w.d < INFINITY);
-        };
-        group(km.p, km.tp, km.p2, km.tp2, wp);
-        group(km.n, km.tn, km.n2, km.tn2, wn);
+        group(km.p, km.tp, km.p2, km.tp2, km.p3, wp);
+        group(km.n, km.tn, km.n2, km.tn2, km.n3, wn);
     }
     if (unsafe) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
         wp = Best1();
