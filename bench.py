@@ -1,28 +1,39 @@
 #!/usr/bin/env python3
-"""bench.py -- samples/s of nearest-prototype assignment (BASELINE.json metric) on N MI355X.
+"""bench.py -- samples/s of nearest-prototype assignment (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W            # starts its own N rank processes when N > 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W     # or under a launcher (RANK / WORLD_SIZE set)
 
-A step = one pass of the hot path over this rank's resident synthetic shard (inputs already in
-HBM): N=1 runs BASELINE.json configs[1], "GLVQ predict, synthetic 10M x 128 fp32, 256 prototypes".
-With N ranks every rank holds its own 10M x 128 shard (weak scaling), prototypes replicated, and
-the only exchange is the RCCL all-gather of winner indices + distances.  It runs on a side stream
-out of one of two alternating result buffers, so the gather of pass k overlaps the kernel of pass
-k+1 (the kernel claims its batches from a queue, so CUs the gather occupies at launch cost only
-their share of the work).  All gathers have completed before the timed region ends.
+A step = one pass of the hot path over this rank's resident synthetic shard (inputs already in HBM).  N=1 runs
+BASELINE.json configs[1], "GLVQ predict, synthetic 10M x 128 fp32, 256 prototypes".  One process per GPU; every sample
+is independent (src/glvq/glvq.rs:224-232), so samples are sharded, the model is replicated, and the only exchange is
+the RCCL all-gather of winner indices + distances.  It runs on a side stream out of one of two alternating result
+buffers, so the gather of pass k overlaps the kernel of pass k+1.  All gathers have completed before the timed region
+ends.
+  --scaling weak    (default) every rank holds min(config N, 10M) rows: per-GPU work fixed
+  --scaling strong  the config's own N split over the ranks, ceil(N / world) rows each: configs[3] (c4, 100M x 256) and
+                    configs[4] (c5, 50M x 128) are fixed-size jobs
 
 One JSON line on rank 0: the contract fields plus
-  roofline     dominant kernel (k_resident_pipe for c2, k_omega_pipe c3, k_lowrank_pipe c4, k_engine c5) against the f32 MFMA peak: algorithmic flops per launch
-               (2*K*D per sample) / mean launch time from HIP events on the launch stream
-  cpu_baseline the f64 oracle (a C port of the reference's loops; the Rust reference cannot be built
-               here) timed on a bounded sample on this box's host cores, rank 0, N=1 only.
+  roofline     the dominant kernel against the roofline that bounds it: algorithmic flops (or bytes) per launch
+                / mean launch time from HIP events on the launch stream; `traffic` = HBM bytes per launch
+               from the PMC counters, collected live by two child runs under rocprofv3 (N=1 only; null when that fails)
+  cpu_baseline the f64 oracle (a C port of the reference's loops; the Rust reference cannot be built here) timed on
+               bounded samples on this box's host cores, rank 0, N=1 only: faithful 1 core (Lambda rebuilt per pair like
+               src/helpers.rs:38), hoisted-Lambda 1 core, hoisted all cores
+  extra        N=1 only: the other BASELINE configs (c3, a c4 shard, a c5 shard) and the HBM-leaning Euclidean case
+               (c2k32), each timed the same way with its own roofline block
 """
 import argparse
 import json
 import os
+import shutil
+import signal
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -31,9 +42,79 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA, dense
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
 # device function behind each kernel family name reported by vqhip_last_kernel
-KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds_staged": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "mfma_omega_lds": "k_omega_pipe",
-             "mfma_omega_lowrank_lds": "k_lowrank_pipe", "scalar": "k_assign_scalar"}
+KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds_staged": "k_resident_pipe",
+             "mfma_euclid_lds_pipe_cut": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "mfma_omega_lds": "k_omega_pipe",
+             "mfma_omega_lowrank_lds": "k_lowrank_pipe", "mfma_euclid_long": "k_long", "mfma_omega_long": "k_omega_long",
+             "mfma_local_long": "k_local_long", "scalar": "k_assign_scalar"}
+HBM_BOUND = {"c2k32", "c2k8"}    # few prototypes: the memory pipe binds, not the matrix pipe
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", help="config name in vq_amd.synth.CONFIGS")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (overrides --scaling's choice)")
+    ap.add_argument("--gather-chunks", type=int, default=1, help="chunks per step when N > 1 (finer gather overlap)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the gather path (side stream, events, RCCL all_gather) even with one rank: rehearsal on a 1-GPU box")
+    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the faithful CPU baseline sample (0 = no CPU baseline)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configs (N=1 runs them by default)")
+    ap.add_argument("--traffic", choices=("live", "off"), default="live",
+                    help="live: two child runs under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE) for roofline.traffic, N=1 only")
+    ap.add_argument("--standin", action="store_true",
+                    help="no GPU: ranks on the CPU over gloo, the assignment replaced by the known answer of the structured "
+                         "data (row g -> prototype g mod K).  Exercises launcher, sharding, gather and the JSON line only")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------ the launcher (no GPU call in this process)
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes (this process has made no
+    GPU call and makes none), wait for them, pass rank 0's JSON line through on the shared stdout."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, start_new_session=True))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:                       # one rank failed: the others would wait in a collective for ever
+                        try:
+                            os.killpg(q.pid, signal.SIGTERM)
+                        except ProcessLookupError:
+                            pass
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+    return rc
+
+
+# ------------------------------------------------------------------ per-sample work (SURVEY.md 8d)
 
 def flops_per_sample(cfg):
     if cfg.omega == "none":
@@ -47,19 +128,121 @@ def bytes_per_sample(cfg):
     return cfg.D * 4 + 8                                      # sample row in, u32 index + f32 distance out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", help="config name in vq_amd.synth.CONFIGS")
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the config's N, capped at 10M)")
-    ap.add_argument("--gather-chunks", type=int, default=1, help="chunks per step when N > 1 (finer gather overlap)")
-    ap.add_argument("--force-gather", action="store_true",
-                    help="run the gather path (side stream, events, RCCL all_gather) even with one rank: rehearsal on a 1-GPU box")
-    ap.add_argument("--cpu-rows", type=int, default=-1, help="rows of the CPU baseline sample (0 = skip)")
-    args = ap.parse_args()
+def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=None):
+    fl, by = flops_per_sample(cfg), bytes_per_sample(cfg)
+    tflops = rows * fl / (launch_ms * 1e-3) / 1e12
+    gbs = rows * by / (launch_ms * 1e-3) / 1e9
+    blk = {"kernel": KERNEL_FN.get(kernel, "k_engine"), "launch_ms": launch_ms, "samples_per_launch": rows,
+           "flops_per_sample": fl, "bytes_per_sample": by, "traffic": traffic, "traffic_source": traffic_source,
+           "tflops": tflops, "mfma_frac_of_157.3": tflops / PEAK_F32_MFMA_TFLOPS,
+           "hbm_GBps_algorithmic": gbs, "hbm_frac_of_8TBps": gbs / PEAK_HBM_GBS}
+    if cfg.name in HBM_BOUND:
+        blk.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
+    else:
+        blk.update({"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tflops / PEAK_F32_MFMA_TFLOPS})
+    return blk
 
+
+# ------------------------------------------------------------------ HBM traffic from the PMC counters, live
+
+def measure_traffic(workload, rows, kernel_fn):
+    """HBM bytes per launch of the dominant kernel: FETCH_SIZE and WRITE_SIZE in one rocprofv3 --pmc pass each (they do
+    not fit one pass), each pass a fresh child run of this script; MI355X_MICROARCH.md (HBM): the counters are in KiB,
+    FETCH_SIZE reports half of a wide coalesced read stream on gfx950 and is doubled, WRITE_SIZE is exact."""
+    import csv
+    import glob
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="vqhip_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--workload", workload, "--rows", str(rows), "--steps", "2", "--warmup", "1", "--cpu-rows", "0", "--no-extras",
+               "--traffic", "off"]
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                return None, f"rocprofv3 --pmc {counter} timed out"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode})"
+            got = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                   if ("vq::" + kernel_fn + "<") in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            if not got:
+                return None, f"no {counter} rows for {kernel_fn}"
+            vals[counter] = sum(got) / len(got)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "live: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, KiB, this run"
+
+
+def stored_traffic(workload):
+    """A committed PMC profile of this workload (profiles/pmc_latest.json), named as the source."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(workload)
+        if e:
+            return e["hbm_bytes_per_launch"], "stored: profiles/" + e.get("from", "pmc_latest.json")
+    except Exception:
+        pass
+    return None, None
+
+
+# ------------------------------------------------------------------ CPU baselines (the oracle as the timed thing)
+
+def cpu_baselines(cfg, model, first_row, faithful_rows, gpu_idx, budget_s=4.0):
+    """(i) faithful single thread (Lambda rebuilt per (sample, prototype) pair, helpers.rs:38 -- the
+    reference's real cost), (ii) hoisted Lambda single thread, (iii) hoisted over all host cores.  Each on a sample sized
+    for about budget_s seconds; rates are per second of wall clock on that sample."""
+    import numpy as np
+
+    import oracle                                   # the checker, used here only as the timed CPU baseline
+    from vq_amd import synth
+
+    cores = min(oracle.max_threads(), os.cpu_count() or 1, 16)     # the GPU box gives one GPU 16 host cores
+
+    def macs(hoist):                                 # multiply-adds per sample
+        if cfg.omega == "none":
+            return cfg.K * cfg.D
+        lam = cfg.M * cfg.D * cfg.D                  # building Lambda = Omega^T Omega once
+        return cfg.K * ((0 if hoist else lam) + cfg.D * cfg.D + cfg.D)
+
+    def run(rows, hoist, threads):
+        rows = max(4, int(rows))
+        Xs = synth.samples_host(model, first_row, rows)
+        t = time.perf_counter()
+        idx, _, _ = oracle.assign(Xs, model.W, omega=model.omega, hoist=hoist, threads=threads)
+        dt = time.perf_counter() - t
+        return rows, dt, idx
+
+    rate1 = 3e9 if cfg.omega == "none" else 6e8      # multiply-adds per second and core, -O2 scalar f64 (measured order of magnitude)
+    out = {}
+    rows, dt, idx = run(faithful_rows if faithful_rows > 0 else budget_s * rate1 / macs(False), False, 1)
+    same = bool((idx.view(np.int32) == gpu_idx[:rows]).all()) if gpu_idx is not None else None
+    out.update({"value": rows / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+                "sample": f"first {rows} rows of the same shard, f64 oracle, faithful mode (Lambda rebuilt per pair where "
+                          f"Omega is used, src/helpers.rs:38), {dt:.1f} s", "indices_equal_gpu": same})
+    if cfg.omega != "none":
+        rows, dt, _ = run(budget_s * rate1 / macs(True), True, 1)
+        out["hoisted_1core"] = {"value": rows / dt, "unit": "samples/s", "cores": 1,
+                                "sample": f"{rows} rows, Lambda built once per model, {dt:.1f} s"}
+    else:
+        out["hoisted_1core"] = {"value": out["value"], "unit": "samples/s", "cores": 1, "sample": "no Omega: same as the faithful leg"}
+    rows, dt, _ = run(budget_s * rate1 * cores * 0.7 / macs(True), True, cores)
+    out["all_cores"] = {"value": rows / dt, "unit": "samples/s", "cores": cores,
+                        "sample": f"{rows} rows, hoisted Lambda, {cores} threads over samples (the reference itself is single-threaded), {dt:.1f} s"}
+    return out
+
+
+# ------------------------------------------------------------------ one rank
+
+def run_rank(args):
     # stdout carries exactly one JSON line: libraries that write banners to fd 1 (RCCL prints its version
     # there at communicator set-up) are pointed at stderr for the duration of the run
     sys.stdout.flush()
@@ -70,34 +253,54 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from vq_amd import Context, synth
+    from vq_amd import synth
     from vq_amd.dist import gather_chunk, make_sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    standin = args.standin
+    if standin:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     gather = world > 1 or args.force_gather
+    exchange = "none"
     if gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if standin:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            exchange = f"gloo all_gather(idx u32, dist f32), {dist.get_world_size()} ranks (CPU stand-in)"
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            exchange = f"rccl {ver} all_gather(idx u32, dist f32), {dist.get_world_size()} ranks over {dist.get_backend()}"
 
     cfg = synth.CONFIGS[args.workload]
-    rows = args.rows or min(cfg.N, 10_000_000)
+    if args.rows:
+        rows = args.rows
+    elif args.scaling == "strong":
+        rows = (cfg.N + world - 1) // world
+    else:
+        rows = min(cfg.N, 10_000_000)
+    if rows * cfg.D * 4 > 200e9:
+        raise SystemExit(f"{rows} rows x {cfg.D} f32 do not fit one GPU next to the results: use more GPUs or --rows")
     sh = make_sharding(rows, world, rank, 1 if world == 1 else args.gather_chunks)
     chunks, m_rows, rows = sh.chunks, sh.rows_per_chunk, sh.rows_per_rank
 
-    ctx = Context(local_rank)
     model = synth.make_model(cfg)
-    synth.load_model(ctx, model)
-
-    # Block-cyclic sharding: chunk c of rank r = global rows [(c*world + r)*m, +m), so the all-gather of
-    # chunk c lands as the contiguous global range [c*world*m, (c+1)*world*m): natural order, no copies.
-    X = [synth.samples_device(ctx, model, sh.first_row(c), m_rows) for c in range(chunks)]
+    ctx = None
+    if standin:
+        X = [None] * chunks
+    else:
+        from vq_amd import Context
+        ctx = Context(local_rank)
+        synth.load_model(ctx, model)
+        # Block-cyclic sharding: chunk c of rank r = global rows [(c*world + r)*m, +m), so the all-gather of
+        # chunk c lands as the contiguous global range [c*world*m, (c+1)*world*m): natural order, no copies.
+        X = [synth.samples_device(ctx, model, sh.first_row(c), m_rows) for c in range(chunks)]
     # two result buffers per chunk, alternating by pass: the gather of pass k reads one while pass k+1 writes the other
     idx_buf = [[torch.empty(m_rows, dtype=torch.int32, device=dev) for _ in range(chunks)] for _ in range(2)]
     dst_buf = [[torch.empty(m_rows, dtype=torch.float32, device=dev) for _ in range(chunks)] for _ in range(2)]
@@ -105,13 +308,22 @@ def main():
     if gather:
         idx_all = torch.empty(sh.total_rows, dtype=torch.int32, device=dev)
         dst_all = torch.empty(sh.total_rows, dtype=torch.float32, device=dev)
+    if gather and not standin:
         comm = torch.cuda.Stream(device=dev)
         computed = [torch.cuda.Event() for _ in range(chunks)]
         gathered = [[torch.cuda.Event() for _ in range(chunks)] for _ in range(2)]
-    compute = torch.cuda.current_stream(dev)
+    compute = None if standin else torch.cuda.current_stream(dev)
     kernel_ms = []                                   # (start, end) event pairs around every launch
 
     passes = [0]
+
+    def assign(c, idx_out, dst_out):
+        if standin:                                  # the known answer of the structured data, no kernel
+            g0 = sh.first_row(c)
+            idx_out.copy_((torch.arange(g0, g0 + m_rows) % cfg.K).to(torch.int32))
+            dst_out.fill_(0.0)
+        else:
+            ctx.assign_into(X[c], idx_out, dst_out)
 
     def step(timed):
         nonlocal idx_loc, dst_loc
@@ -119,12 +331,17 @@ def main():
         passes[0] += 1
         idx_loc, dst_loc = idx_buf[par], dst_buf[par]
         for c in range(chunks):
+            if standin:
+                assign(c, idx_loc[c], dst_loc[c])
+                if gather:
+                    gather_chunk(sh, c, idx_all, dst_all, idx_loc[c], dst_loc[c])
+                continue
             if gather:
                 compute.wait_event(gathered[par][c])     # the gather two passes ago has read this buffer
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(compute)
-            ctx.assign_into(X[c], idx_loc[c], dst_loc[c])
+            assign(c, idx_loc[c], dst_loc[c])
             if timed:
                 e1.record(compute)
                 kernel_ms.append((e0, e1))
@@ -138,9 +355,10 @@ def main():
     def fence():
         if gather:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not standin:
+            torch.cuda.synchronize(dev)
 
-    if gather:
+    if gather and not standin:
         for par in range(2):
             for e in gathered[par]:
                 e.record(comm)
@@ -167,66 +385,95 @@ def main():
             want = (torch.arange(sh.total_rows, device=dev) % cfg.K).to(torch.int32)
             assert bool((idx_all == want).all()), "gathered assignment is wrong"
 
-    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
     if rank == 0:
-        total_rows = rows * world
-        fl = flops_per_sample(cfg)
-        achieved = m_rows * fl / (launch_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kernel = "stand-in (no kernel)" if standin else ctx.last_kernel
         line = {
             "metric": "samples/sec nearest-prototype assignment",
-            "value": total_rows * args.steps / elapsed,
+            "value": rows * world * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if not args.rows else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not standin else "synthetic, CPU stand-in for the kernel (launcher / gather rehearsal, not a measurement)",
             "config": {"workload": f"{cfg.model} predict, synthetic {rows}x{cfg.D} f32 per GPU, {cfg.K} prototypes"
                                    + (f", Omega {cfg.M}x{cfg.D} ({cfg.omega})" if cfg.omega != "none" else ""),
-                       "name": cfg.name, "rows_per_gpu": rows, "dim": cfg.D, "prototypes": cfg.K,
-                       "gather_chunks": chunks, "kernel": ctx.last_kernel,
-                       "exchange": "rccl all_gather(idx u32, dist f32)" if gather else "none"},
-            "roofline": {"bound": "mfma", "kernel": KERNEL_FN.get(ctx.last_kernel, "k_engine"), "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "launch_ms": launch_ms, "flops_per_sample": fl, "samples_per_launch": m_rows,
-                         "hbm_GBps_algorithmic": m_rows * bytes_per_sample(cfg) / (launch_ms * 1e-3) / 1e9,
-                         "hbm_frac_of_8TBps": m_rows * bytes_per_sample(cfg) / (launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                       "name": cfg.name, "rows_per_gpu": rows, "total_rows": rows * world, "dim": cfg.D, "prototypes": cfg.K,
+                       "gather_chunks": chunks, "kernel": kernel, "exchange": exchange},
         }
-        cpu_rows = args.cpu_rows
-        if cpu_rows < 0:
-            # ~15 s of single-core work: K*D multiply-adds per sample (Euclidean), K*(M*D*D + D*D) when
-            # Lambda is rebuilt for every (sample, prototype) pair like src/helpers.rs:38
-            per_sample = cfg.K * cfg.D if cfg.omega == "none" else cfg.K * (cfg.M * cfg.D * cfg.D + cfg.D * cfg.D)
-            cpu_rows = 0 if world > 1 else max(16, int(4.5e10 / per_sample))
-        if cpu_rows:
-            import oracle                                   # the checker, used here only as the timed CPU baseline
-
-            cpu_rows = min(cpu_rows, m_rows)
-            Xs = synth.samples_host(model, sh.first_row(0), cpu_rows)
-            t1 = time.perf_counter()
-            o_idx, _, _ = oracle.assign(Xs, model.W, omega=model.omega, hoist=False, threads=1)
-            cpu_s = time.perf_counter() - t1
-            same = bool((o_idx.view(np.int32) == idx_loc[0][:cpu_rows].cpu().numpy()).all())
-            line["cpu_baseline"] = {"value": cpu_rows / cpu_s, "unit": "samples/s", "cores": 1, "kind": "port",
-                                    "sample": f"first {cpu_rows} rows of the same shard, f64 oracle, faithful mode "
-                                              f"(Lambda rebuilt per pair where Omega is used), {cpu_s:.1f} s",
-                                    "indices_equal_gpu": same}
+        if not standin:
+            launch_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ms]))
+            traffic, source = None, None
+            if world == 1 and args.traffic == "live":
+                traffic, source = measure_traffic(args.workload, rows, KERNEL_FN.get(kernel, "k_engine"))
+            if traffic is None and m_rows == min(cfg.N, 10_000_000):
+                why = source
+                traffic, source = stored_traffic(args.workload)
+                if traffic is not None and why:
+                    source += f" (live collection: {why})"
+            line["roofline"] = roofline_block(cfg, kernel, m_rows, launch_ms, traffic, source)
+            if world == 1 and args.cpu_rows != 0:
+                line["cpu_baseline"] = cpu_baselines(cfg, model, sh.first_row(0), args.cpu_rows if args.cpu_rows > 0 else 0,
+                                                     idx_loc[0].cpu().numpy(), budget_s=6.0)
+    # the other configs, one GPU: same timing, own roofline blocks
+    if rank == 0 and world == 1 and not standin and not args.no_extras and args.workload == "c2":
+        del X, idx_buf, dst_buf
+        torch.cuda.empty_cache()
+        line["extra"] = {}
+        for name, xrows in (("c3", 10_000_000), ("c4", 10_000_000), ("c5", 4_000_000), ("c2k32", 10_000_000)):
+            xc = synth.CONFIGS[name]
+            xm = synth.make_model(xc)
+            synth.load_model(ctx, xm)
+            Xx = synth.samples_device(ctx, xm, 0, xrows)
+            xi = torch.empty(xrows, dtype=torch.int32, device=dev)
+            xd = torch.empty(xrows, dtype=torch.float32, device=dev)
+            for _ in range(3):
+                ctx.assign_into(Xx, xi, xd)
+            torch.cuda.synchronize(dev)
+            evs = []
+            n_launch = 20 if name != "c5" else 10
+            tw = time.perf_counter()
+            for _ in range(n_launch):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(compute)
+                ctx.assign_into(Xx, xi, xd)
+                e1.record(compute)
+                evs.append((e0, e1))
+            torch.cuda.synchronize(dev)
+            wall = time.perf_counter() - tw
+            ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+            traffic, source = stored_traffic(name) if xrows == 10_000_000 else (None, None)
+            entry = {"workload": f"{xc.model} predict, synthetic {xrows}x{xc.D} f32, {xc.K} prototypes"
+                                 + (f", Omega {xc.M}x{xc.D} ({xc.omega})" if xc.omega != "none" else ""),
+                     "value": xrows * n_launch / wall, "unit": "samples/s", "launches": n_launch, "ms_per_step": wall / n_launch * 1e3,
+                     "kernel": ctx.last_kernel, "roofline": roofline_block(xc, ctx.last_kernel, xrows, ms, traffic, source)}
+            if args.cpu_rows != 0:
+                entry["cpu_baseline"] = cpu_baselines(xc, xm, 0, 0, xi.cpu().numpy(), budget_s=2.5)
+            line["extra"][name] = entry
+            del Xx, xi, xd
+            torch.cuda.empty_cache()
+    if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if gather:
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    have_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if have_launcher and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
+    if args.gpus > 1 and not have_launcher:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -91,6 +91,11 @@ SHAPES = [
     ("liramlvq_r3_d20", "LiRaMLVQ", 300, 20, 6, 3, "global"),
     ("lgmlvq_8x128", "LGMLVQ", 333, 128, 8, 128, "local"),
     ("lgmlvq_small", "LGMLVQ", 257, 10, 5, 10, "local"),
+    # BASELINE.json configs[3] / configs[4] at their own model shapes (rows cut to what the f64 oracle walks in seconds):
+    # K = 1024 is the LDS-capacity edge of k_lowrank_pipe (88 KiB of projected prototypes + 16 KiB of Omega), 64 Omega_j
+    # of 128 x 128 are the 4 MiB stream of k_engine<LOCAL> that does not fit L2 next to the rows
+    ("c4_liramlvq_r16_d256_k1024", "LiRaMLVQ", 1024, 256, 1024, 16, "global"),
+    ("c5_lgmlvq_64x128x128", "LGMLVQ", 1536, 128, 64, 128, "local"),
 ]
 
 
@@ -100,6 +105,7 @@ AUTO_KERNEL = {
     "glvq_d64_k70": "mfma_euclid", "glvq_streamed_k600": "mfma_euclid", "glvq_streamed_d256": "mfma_euclid", "gmlvq_128x128": "mfma_omega", "gmlvq_small_d12": "mfma_omega",
     "liramlvq_r16_d256": "mfma_omega", "liramlvq_r3_d20": "mfma_omega", "lgmlvq_8x128": "mfma_local",
     "lgmlvq_small": "mfma_local",  # D = 10: rows only 4-byte aligned, cut at D inside the kernel
+    "c4_liramlvq_r16_d256_k1024": "mfma_omega_lowrank_lds", "c5_lgmlvq_64x128x128": "mfma_local",
 }
 
 

@@ -5,7 +5,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqhip.so")
+# VQHIP_LIB: another build of the same ABI (A/B timing of two builds on one box); default: the in-tree library
+LIB_PATH = os.environ.get("VQHIP_LIB") or os.path.join(_HERE, "libvqhip.so")
 
 OK, ERR_INVALID, ERR_STATE, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA = 0, 1, 2
