@@ -22,8 +22,9 @@ One JSON line on rank 0: the contract fields plus
   cpu_baseline the f64 oracle (a C port of the reference's loops; the Rust reference cannot be built here) timed on
                bounded samples on this box's host cores, rank 0, N=1 only: faithful 1 core (Lambda rebuilt per pair like
                src/helpers.rs:38), hoisted-Lambda 1 core, hoisted all cores
-  extra        N=1 only: the other BASELINE configs (c3, a c4 shard, a c5 shard) and the HBM-leaning Euclidean case
-               (c2k32), each timed the same way with its own roofline block
+  extra        N=1 only: the other BASELINE configs (c3, a c4 shard, a c5 shard) and the HBM-leaning Euclidean cases
+               (c2k32: 32 prototypes on the matrix cores; c2k8: 8 prototypes, the direct-form kernel), each timed the same way
+               with its own roofline block
 """
 import argparse
 import json
@@ -45,7 +46,7 @@ PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
 KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds_staged": "k_resident_pipe",
              "mfma_euclid_lds_pipe_cut": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "mfma_omega_lds": "k_omega_pipe",
              "mfma_omega_lowrank_lds": "k_lowrank_pipe", "mfma_euclid_long": "k_long", "mfma_omega_long": "k_omega_long",
-             "mfma_local_long": "k_local_long", "scalar": "k_assign_scalar"}
+             "mfma_local_long": "k_local_long", "valu_euclid_direct": "k_direct", "scalar": "k_assign_scalar"}
 HBM_BOUND = {"c2k32", "c2k8"}    # few prototypes: the memory pipe binds, not the matrix pipe
 
 
@@ -424,7 +425,7 @@ def run_rank(args):
         del X, idx_buf, dst_buf
         torch.cuda.empty_cache()
         line["extra"] = {}
-        for name, xrows in (("c3", 10_000_000), ("c4", 10_000_000), ("c5", 4_000_000), ("c2k32", 10_000_000)):
+        for name, xrows in (("c3", 10_000_000), ("c4", 10_000_000), ("c5", 4_000_000), ("c2k32", 10_000_000), ("c2k8", 10_000_000)):
             xc = synth.CONFIGS[name]
             xm = synth.make_model(xc)
             synth.load_model(ctx, xm)

@@ -25,7 +25,7 @@ def ctx():
     c.close()
 
 
-def _check(ctx, X, W, Om=None, cls=None, y=None, atol=0.0, want_prefix="mfma_", exact=False, rows=None):
+def _check(ctx, X, W, Om=None, cls=None, y=None, atol=0.0, want_prefix=("mfma_", "valu_"), exact=False, rows=None):
     """Plain (and, with cls / y, matched) search of X against the oracle; returns the plain report."""
     ctx.set_prototypes(W)
     if Om is not None:
@@ -88,7 +88,7 @@ def test_dense_clusters(ctx, K, D):
     X = (centres[pick] + 3e-3 * np.linalg.norm(centres[pick], axis=1, keepdims=True) * u).astype(np.float32)
     cls = (np.arange(K) % 3).astype(np.uint32)           # cluster members fall into different classes
     y = rng.integers(0, 3, size=N).astype(np.uint32)
-    _check(ctx, X, W, cls=cls, y=y, want_prefix="mfma_euclid")
+    _check(ctx, X, W, cls=cls, y=y, want_prefix=("mfma_euclid", "valu_euclid"))
 
 
 def test_dense_clusters_under_a_global_omega(ctx):
@@ -127,7 +127,7 @@ def test_many_prototypes_in_few_dimensions(ctx, D, K):
     X = rng.uniform(-1, 1, size=(4000, D)).astype(np.float32)
     cls = (np.arange(K) % 4).astype(np.uint32)
     y = rng.integers(0, 4, size=4000).astype(np.uint32)
-    _check(ctx, X, W, cls=cls, y=y, want_prefix="mfma_euclid")
+    _check(ctx, X, W, cls=cls, y=y, want_prefix=("mfma_euclid", "valu_euclid"))
 
 
 def test_reference_initialisation_shape(ctx):
@@ -141,7 +141,7 @@ def test_reference_initialisation_shape(ctx):
     N = 5000
     X = (means[rng.integers(0, classes, size=N)] + 0.3 * rng.uniform(-1, 1, size=(N, D))).astype(np.float32)
     y = rng.integers(0, classes, size=N).astype(np.uint32)
-    _check(ctx, X, W, cls=cls, y=y, want_prefix="mfma_euclid")
+    _check(ctx, X, W, cls=cls, y=y, want_prefix=("mfma_euclid", "valu_euclid"))
 
 
 # ------------------------------------------------------------------ data far from the origin

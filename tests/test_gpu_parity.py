@@ -101,7 +101,7 @@ SHAPES = [
 
 # kernel family VQHIP_KERNEL_AUTO must pick per shape (the MFMA kernels serve every D <= 256)
 AUTO_KERNEL = {
-    "c1_vq_iris_shape": "mfma_euclid", "glvq_128x256": "mfma_euclid", "glvq_ragged_d100_k37": "mfma_euclid",
+    "c1_vq_iris_shape": "valu_euclid_direct", "glvq_128x256": "mfma_euclid", "glvq_ragged_d100_k37": "mfma_euclid",
     "glvq_d64_k70": "mfma_euclid", "glvq_streamed_k600": "mfma_euclid", "glvq_streamed_d256": "mfma_euclid", "gmlvq_128x128": "mfma_omega", "gmlvq_small_d12": "mfma_omega",
     "liramlvq_r16_d256": "mfma_omega", "liramlvq_r3_d20": "mfma_omega", "lgmlvq_8x128": "mfma_local",
     "lgmlvq_small": "mfma_local",  # D = 10: rows only 4-byte aligned, cut at D inside the kernel
@@ -351,8 +351,9 @@ def test_pipelined_kernel_prototype_counts(ctx, K):
     ctx.set_kernel_policy(KERNEL_AUTO)
     ctx.set_prototypes(W)
     idx, dist = ctx.assign(X)
-    # one tile of prototypes leaves room in LDS for the rows: they are staged through it (k_resident_pipe STAGED)
-    assert ctx.last_kernel == ("mfma_euclid_lds_staged" if K <= 32 else "mfma_euclid_lds_pipe")
+    # at most 8 prototypes: the direct-form kernel; one tile of prototypes leaves room in LDS for the rows: they are
+    # staged through it (k_resident_pipe STAGED)
+    assert ctx.last_kernel == ("valu_euclid_direct" if K <= 8 else "mfma_euclid_lds_staged" if K <= 32 else "mfma_euclid_lds_pipe")
     rep = parity.compare(idx, dist, *oracle.assign(X, W, threads=8))
     assert rep.ok, str(rep)
     y = rng.integers(0, 3, size=N).astype(np.uint32)
@@ -805,7 +806,7 @@ def test_euclid_and_local_dispatch_grids(ctx):
         for K in (1, 2, 33, 256, 257, 1000, 5000):
             W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
             # (thousands of random prototypes on a line included: crowded samples take the kernels' exact scan)
-            ak = _auto_vs_scalar(ctx, Xd, N, lambda: ctx.set_prototypes(W), (D, K), "mfma_euclid", rtol=1e-5, atol=1e-7)
+            ak = _auto_vs_scalar(ctx, Xd, N, lambda: ctx.set_prototypes(W), (D, K), ("mfma_euclid", "valu_euclid"), rtol=1e-5, atol=1e-7)
             seen.add(ak)
     for D in (16, 100, 128, 200, 256, 300, 400):
         X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
@@ -820,7 +821,7 @@ def test_euclid_and_local_dispatch_grids(ctx):
                     ctx.set_local_omegas(Oms)
                 seen.add(_auto_vs_scalar(ctx, Xd, N, load, (D, M, K), "mfma_local"))
     ctx.set_kernel_policy(KERNEL_AUTO)
-    assert {"mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local", "mfma_local_long"} <= seen, seen
+    assert {"valu_euclid_direct", "mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local", "mfma_local_long"} <= seen, seen
 
 
 def test_matched_dispatch_grid(ctx):
@@ -849,7 +850,7 @@ def test_matched_dispatch_grid(ctx):
             ctx.set_labels(cls)
             out[policy] = ctx.assign_matched(X, y) + (ctx.last_kernel,)
         s, a = out[KERNEL_SCALAR], out[KERNEL_AUTO]
-        assert s[4] == "scalar" and a[4].startswith("mfma_"), ((D, K, M, kind), s[4], a[4])
+        assert s[4] == "scalar" and a[4].startswith(("mfma_", "valu_")), ((D, K, M, kind), s[4], a[4])
         kernels.add(a[4])
         for si, sd, ai, ad in ((s[0], s[1], a[0], a[1]), (s[2], s[3], a[2], a[3])):
             sd, ad = sd.astype(np.float64), ad.astype(np.float64)
@@ -877,7 +878,7 @@ def test_staged_kernel(ctx, case):
     ctx.set_kernel_policy(KERNEL_AUTO)
     ctx.set_prototypes(W)
     idx, dist = ctx.assign(X)
-    assert ctx.last_kernel == "mfma_euclid_lds_staged"
+    assert ctx.last_kernel == ("mfma_euclid_lds_staged" if K > 8 else "valu_euclid_direct")
     o = oracle.assign(X, W, threads=8)
     rep = parity.compare(idx, dist, *o)
     assert rep.ok, str(rep)
@@ -888,13 +889,21 @@ def test_staged_kernel(ctx, case):
         rep = parity.compare(j, d, *oracle.assign(X, W, proto_cls=cls, labels=y, matching=matching, threads=8))
         assert rep.ok, f"matching={matching}: {rep}"
     os.environ["VQHIP_NO_STAGED"] = "1"                      # same model on the fragment-load kernel
+    os.environ["VQHIP_NO_DIRECT"] = "1"
     try:
         ctx.set_prototypes(W)
         idx2, dist2 = ctx.assign(X)
         assert ctx.last_kernel == "mfma_euclid_lds_pipe"
-    finally:
         del os.environ["VQHIP_NO_STAGED"]
-    assert (idx2 == idx).all() and (dist2.view(np.uint32) == dist.view(np.uint32)).all()
+        ctx.set_prototypes(W)
+        idx3, dist3 = ctx.assign(X)
+        assert ctx.last_kernel == "mfma_euclid_lds_staged"
+    finally:
+        os.environ.pop("VQHIP_NO_STAGED", None)
+        del os.environ["VQHIP_NO_DIRECT"]
+    assert (idx2 == idx3).all() and (dist2.view(np.uint32) == dist3.view(np.uint32)).all()     # staged == fragment loads, bit for bit
+    rep2 = parity.compare(idx2, dist2, *o)
+    assert rep2.ok and (idx2 != idx).sum() <= rep.near_ties + rep2.near_ties, f"{rep} / {rep2}"
 
 
 @pytest.mark.parametrize("D", [1, 2, 3, 5, 10, 30, 63, 101, 126, 255])

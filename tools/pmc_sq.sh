@@ -4,8 +4,8 @@ set -u
 TAG=${1:-sq}; WL=${2:-c2}; export VQHIP_VARIANT=${3:-0}
 R=$PWD; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --cpu-rows 0 > $OUT/sq1.log 2>&1 || { echo "sq1 failed"; tail -5 $OUT/sq1.log; exit 1; }
-timeout -s KILL 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LEVEL_WAVES --output-format csv -d $OUT/sq2 -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --cpu-rows 0 > $OUT/sq2.log 2>&1 || { echo "sq2 failed"; tail -5 $OUT/sq2.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --cpu-rows 0 --no-extras --traffic off > $OUT/sq1.log 2>&1 || { echo "sq1 failed"; tail -5 $OUT/sq1.log; exit 1; }
+timeout -s KILL 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_LEVEL_WAVES --output-format csv -d $OUT/sq2 -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --cpu-rows 0 --no-extras --traffic off > $OUT/sq2.log 2>&1 || { echo "sq2 failed"; tail -5 $OUT/sq2.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 dur = 0

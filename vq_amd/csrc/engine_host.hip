@@ -157,6 +157,29 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     return true;
 }
 
+// At most 8 prototypes over rows of at most 256 values: k_direct (kernels_direct.hip), every distance in the direct
+// form on the vector ALUs.  img1 = KP rows of R floats (the negated prototypes: no centring, no scaling), KP class ids.
+bool bind_direct(EngineModel &m, std::vector<float> &img, const std::vector<float> &W, const std::vector<uint32_t> &cls)
+{
+    // measured against the matrix-core kernels (tools/shape_bench.py, D = 32 .. 256): 1.1 to 1.65 times their rate up to 8
+    // prototypes, level at 12, behind at 16
+    if (m.D > 256 || m.K > 8 || getenv("VQHIP_NO_DIRECT")) return false;
+    const int R = pad_pow2(m.D, 32), KP = m.K <= 4 ? 4 : 8;
+    const LaunchFn fn = direct_launcher(R, KP, &m.samples_per_batch);
+    if (!fn) return false;
+    img.assign((size_t)KP * R + KP, 0.0f);
+    for (uint32_t k = 0; k < m.K; ++k)
+        for (uint32_t d = 0; d < m.D; ++d) img[(size_t)k * R + d] = -W[(size_t)k * m.D + d];     // x + (-w): one packed add
+    for (uint32_t k = 0; k < (uint32_t)KP; ++k) {
+        const uint32_t c = k < m.K && !cls.empty() ? cls[k] : 0xFFFFFFFFu;
+        std::memcpy(&img[(size_t)KP * R + k], &c, 4);
+    }
+    m.ngroups1 = 1;
+    m.launch = fn;
+    m.name = "valu_euclid_direct";
+    return true;
+}
+
 // Rows above 256 values: k_long.  img1 = A-fragment pieces of -2 W, one 1 KiB piece per (group of 8 tiles when there
 // are more than 8, chunk of 128 or 64 values, tile of 32 prototypes, step): lane (row, h) of step j holds values
 // 4 (2 j + h) .. + 3 of the chunk; img2 = the tiles' tails (||w_k||^2 / class ids); plain rows padded to whole chunks.
@@ -398,6 +421,17 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
     // the coordinates everything below lives in: the caller's, or shifted by the mean prototype (centre_prototypes).
     // Rows above 256 values keep the caller's coordinates (the long-row kernels fetch their rows in chunks, twice).
     std::vector<float> mu, Wc;
+    if (omega_kind == OMEGA_NONE && bind_direct(m, img1, Win, cls)) {         // nothing to screen, nothing to centre
+        m.mode = MODE_EUCLID;
+        EngineModel *out = new EngineModel(m);
+        herr = to_device(&out->img1, img1);
+        if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, QUEUE_SLOTS * QUEUE_STRIDE * sizeof(uint32_t));
+        if (herr != hipSuccess) {
+            engine_free(out);
+            return nullptr;
+        }
+        return out;
+    }
     const bool centred = D <= 256 && centre_prototypes(Win, K, D, mu, Wc);
     const std::vector<float> &W = centred ? Wc : Win;
 
@@ -534,7 +568,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.wmax2 = m->wmax2;
     a.dbg = nullptr;
     static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
-    if (variant_env() == 31 && !queue) {
+    if ((variant_env() == 31 || variant_env() == 32) && !queue) {
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
@@ -553,7 +587,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
             for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
         double tot = 0;
         for (int i = 0; i < 7; ++i) tot += sum[i];
-        if (variant_env() == 31) {
+        if (variant_env() == 31 || variant_env() == 32) {
             double s4[6] = {0};
             for (size_t w = 0; w < (size_t)256 * (getenv("VQHIP_NW4") ? 4 : 8); ++w)
                 for (int i = 0; i < 6; ++i) s4[i] += (double)h[w * 8 + i];

@@ -259,6 +259,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         static_for<0, (int)BLOCK>([&](auto qq) { fetch(qq, block0 + decltype(qq)::value); });
     }
 
+    // store instructions a batch issues (wave-uniform): idx and dist by different lane halves, the labelled search two more
+    const uint32_t stores_per_batch = (a.out.idx ? 1u : 0u) + (a.out.dist ? 1u : 0u) +
+                                      (MATCHED ? (a.out.jneg ? 1u : 0u) + (a.out.dneg ? 1u : 0u) : 0u);
+    uint32_t stores_behind = 0u;                       // STAGED: store instructions issued after the pieces now in flight
     while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
         const uint64_t nb0 = queue.take();             // first batch of the next block (the wait for its atomic is here)
         static_for<0, (int)BLOCK>([&](auto qq) {
@@ -273,22 +277,30 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 for (int j = 0; j < R / 8; ++j) xf[j] = mask_chunk(xf[j], (uint32_t)(2 * j + h), a.D);
             }
             if constexpr (STAGED) {
-                // everything older than the stores of the previous batch has landed, the pieces among it; the
-                // fragments are out of the buffer (lgkmcnt) before the next batch's pieces are sent into it
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // This batch's pieces have landed: vmcnt counts in issue order and the only requests younger than the
+                // pieces are the result stores of the previous batch, which need not be waited for (their round trip to
+                // L2, every batch, costs the streaming rate 13 %: tools/hbm_stream.hip).  The fragments are out of the
+                // buffer (lgkmcnt) before the next batch's pieces are sent into it.
+                switch (stores_behind) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                }
                 const char *rowp = stage + St::row_off(s_col) + h * 16;
 #pragma unroll
                 for (int j = 0; j < R / 8; ++j) xf[j] = *(const f32x4 *)(rowp + 32 * j);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             if (centred) centre_fragment<R / 8, 2>(xf, mu_lds, h);
+            const uint32_t label = ln[q];
 #pragma unroll
             for (int j = 0; j < R / 8; ++j) {
                 const f32x2 lo = {xf[j][0], xf[j][1]}, hi = {xf[j][2], xf[j][3]};
                 ss2 = __builtin_elementwise_fma(lo, lo, ss2);
                 ss2 = __builtin_elementwise_fma(hi, hi, ss2);
             }
-            const uint32_t label = ln[q];
             float ss = ss2[0] + ss2[1];
             ss += xor32(ss);                           // ||x||^2, the same value in both lanes of the pair
             const bool unsafe = !(ss < a.ss_limit);    // NaN / INF / huge rows: exact scan at the end
@@ -322,6 +334,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                     if (a.out.dist) put(a.out.dist + b * 32, __builtin_bit_cast(uint32_t, wp.d));
                     if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
                 }
+                stores_behind = stores_per_batch;
             }
             // this set's rows are dead: refill it for the same position of the next block
             if constexpr (SINGLE) {
@@ -366,7 +379,9 @@ hipError_t launch_resident_staged(const EngineArgs &a, bool matched, hipStream_t
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    if (matched)
+    if (R == 128 && a.dbg && !matched)                               // diagnostic build (VQHIP_VARIANT=32): phase stamps
+        hipLaunchKernelGGL((k_resident_pipe<128, false, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    else if (matched)
         hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
     else
         hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, true>), dim3(grid), dim3(512), 0, st, a);

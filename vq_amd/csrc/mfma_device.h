@@ -507,6 +507,62 @@ __device__ __forceinline__ float exact_sq_lds(const f32x4 (&xf)[R / 8], const fl
     return t + xor32(t);
 }
 
+// The same for two rows at once (two independent accumulation chains).
+template <int R>
+__device__ __forceinline__ void exact_sq_lds2(const f32x4 (&xf)[R / 8], const float *img, uint32_t ka, uint32_t kb, int h, float &da, float &db)
+{
+    using Gm = Geom<R>;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const float *ra = img + (size_t)(ka >> 5) * Gm::TILE_FLOATS + Gm::chunk_off((int)(ka & 31u), h);
+    const float *rb = img + (size_t)(kb >> 5) * Gm::TILE_FLOATS + Gm::chunk_off((int)(kb & 31u), h);
+    f32x2 pa = {0.0f, 0.0f}, pb = {0.0f, 0.0f};
+    const f32x2 half = {0.5f, 0.5f};
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 va = *(const f32x4 *)(ra + 8 * j), vb = *(const f32x4 *)(rb + 8 * j);      // -2 w
+        const f32x2 xl = {xf[j][0], xf[j][1]}, xh = {xf[j][2], xf[j][3]};
+        const f32x2 a0 = __builtin_elementwise_fma(half, f32x2{va[0], va[1]}, xl), a1 = __builtin_elementwise_fma(half, f32x2{va[2], va[3]}, xh);
+        const f32x2 b0 = __builtin_elementwise_fma(half, f32x2{vb[0], vb[1]}, xl), b1 = __builtin_elementwise_fma(half, f32x2{vb[2], vb[3]}, xh);
+        pa = __builtin_elementwise_fma(a0, a0, pa);
+        pb = __builtin_elementwise_fma(b0, b0, pb);
+        pa = __builtin_elementwise_fma(a1, a1, pa);
+        pb = __builtin_elementwise_fma(b1, b1, pb);
+    }
+    const float ta = pa[0] + pa[1], tb = pb[0] + pb[1];
+    da = ta + xor32(ta);
+    db = tb + xor32(tb);
+}
+
+// helpers.rs:55-77 / 91-132 in f32 against an LDS-resident image: every prototype in index order, direct (x - w)^2
+// form, strict '<' from (0, +INF).  The answer for samples the screening cannot settle (finish_keys), and the whole
+// search where the model has so few prototypes that walking them costs less than the matrix cores' 32-row tile
+// (EngineArgs::direct).  Two prototypes per step; same sums per prototype as exact_sq_lds, so the result does not
+// depend on which of the two paths measured it.
+template <int R, bool MATCHED, bool ROOT>
+__device__ __forceinline__ void scan_exact_lds(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h, Best1 &wp,
+                                               Best1 &wn)
+{
+    using Gm = Geom<R>;
+    wp = Best1();
+    wn = Best1();
+    auto cls_of = [&](uint32_t k) { return ((const uint32_t *)(img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::W_FLOATS))[32 + (k & 31)]; };
+    for (uint32_t k = 0; k < K; k += 2) {
+        const uint32_t kb = k + 1 < K ? k + 1 : k;
+        float da, db;
+        exact_sq_lds2<R>(xf, img, k, kb, h, da, db);
+        if (ROOT) {
+            da = sqrtf(da);
+            db = sqrtf(db);
+        }
+        if (!MATCHED || cls_of(k) == label) wp.offer(da, k);
+        else wn.offer(da, k);
+        if (kb != k) {
+            if (!MATCHED || cls_of(kb) == label) wp.offer(db, kb);
+            else wn.offer(db, kb);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ pipelined tile step of the resident kernels
 // Same contract as k_resident.  What it is built around (measured on MI355X):
 //   * v_mfma_f32_32x32x2_f32 runs at the f32 vector rate and does not co-execute with VALU work of
@@ -667,7 +723,6 @@ template <int R, bool MATCHED, bool ROOT = true>
 __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h,
                                             bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
 {
-    using Gm = Geom<R>;
     // helpers.rs:23 (rooted) vs helpers.rs:44 (squared)
     auto dist = [&](uint32_t k) {
         const float d = exact_sq_lds<R>(xf, img, k, h);
@@ -704,16 +759,7 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         group(km.p, km.tp, km.p2, km.tp2, km.p3, wp);
         group(km.n, km.tn, km.n2, km.tn2, km.n3, wn);
     }
-    if (unsafe) {       // exact scan in index order (helpers.rs:55-77 in f32), rows from LDS
-        wp = Best1();
-        wn = Best1();
-        for (uint32_t k = 0; k < K; ++k) {
-            const float d = dist(k);
-            const uint32_t ck = MATCHED ? ((const uint32_t *)(img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::W_FLOATS))[32 + (k & 31)] : 0u;
-            if (!MATCHED || ck == label) wp.offer(d, k);
-            else wn.offer(d, k);
-        }
-    }
+    if (unsafe) scan_exact_lds<R, MATCHED, ROOT>(xf, img, K, label, h, wp, wn);      // helpers.rs:55-77 in f32, rows from LDS
 }
 
 }  // namespace

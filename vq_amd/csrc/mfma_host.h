@@ -23,6 +23,8 @@ LaunchFn resident_cut_launcher(int R);                                          
 LaunchFn resident_staged_launcher(int R, size_t *staging_bytes);
 LaunchFn omega_pipe_launcher(int R);                                             // kernels_omega.hip: k_omega_pipe
 LaunchFn lowrank_launcher(int R1);                                               // kernels_omega.hip: k_lowrank_pipe
+// kernels_direct.hip: k_direct (at most 8 prototypes, direct form on the vector ALUs); R in {32, 64, 128, 256}, KP in {4, 8}
+LaunchFn direct_launcher(int R, int KP, int *samples_per_batch);
 LaunchFn long_launcher(int tiles);                                               // kernels_long.hip: k_long (rows above 256 values)
 LaunchFn local_long_launcher(int tiles);    // k_local_long<tiles>: LGMLVQ over rows above 256 values
 LaunchFn omega_long_launcher(int R2);                                            // kernels_long.hip: k_omega_long
