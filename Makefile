@@ -10,11 +10,34 @@ OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_engine.o $(CS
             $(CSRC)/kernels_project.o $(CSRC)/engine_host.o $(CSRC)/synth.o
 HDRS     := $(CSRC)/vq_common.h $(CSRC)/engine.h $(CSRC)/mfma_device.h $(CSRC)/mfma_host.h $(CSRC)/mfma_images.h include/vqhip.h
 LIB      := vq_amd/libvqhip.so
+# the same objects as a static archive: what a build.rs links with `cargo:rustc-link-lib=static=vqhip`
+LIBA     := vq_amd/libvqhip.a
+ROCM_LIB ?= /opt/rocm/lib
 
 MODELS_TEST := tests/cpp/test_models
 ROWS_BENCH  := tools/host_rows_bench
 
-all: $(LIB) oracle $(MODELS_TEST) $(ROWS_BENCH)
+MODELS_TEST_STATIC := tests/cpp/test_models_static
+
+all: $(LIB) $(LIBA) oracle $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream asan
+
+$(LIBA): $(OBJS)
+	rm -f $@ && ar rcs $@ $(OBJS)
+
+# the C++ mirror's tests linked against the ARCHIVE with plain g++, the way a Rust build would link it:
+# the archive + the HIP runtime + the C++ runtime, nothing else
+$(MODELS_TEST_STATIC): tests/cpp/test_models.cpp include/vq_models.hpp include/vqhip.h $(LIBA)
+	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ $(LIBA) -L$(ROCM_LIB) -lamdhip64 -lpthread -Wl,-rpath,$(ROCM_LIB)
+
+tools/hbm_stream: tools/hbm_stream.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
+
+# host-side code of the library (the image builders, duplicate detection, centring) under AddressSanitizer and UBSan,
+# CPU only: tests/cpp/test_host_asan.cpp drives engine_build's host half without a device
+asan: tests/cpp/test_host_asan
+tests/cpp/test_host_asan: tests/cpp/test_host_asan.cpp $(CSRC)/engine_host.hip $(HDRS)
+	$(HIPCC) -O1 -g -std=c++17 --offload-arch=$(ARCH) -fno-gpu-sanitize -fsanitize=address,undefined -fno-omit-frame-pointer \
+	    -Iinclude -I$(CSRC) -DVQHIP_HOST_TEST $< -o $@
 
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
@@ -37,7 +60,7 @@ oracle:
 	$(MAKE) -C oracle -s libvqoracle.so
 
 clean:
-	rm -f $(OBJS) $(LIB) $(MODELS_TEST) $(ROWS_BENCH)
+	rm -f $(OBJS) $(LIB) $(LIBA) $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream tests/cpp/test_host_asan
 	$(MAKE) -C oracle -s clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean asan

@@ -23,13 +23,16 @@
 // it out of scope).  A fitted state is installed with `from_fitted(...)`: the prototypes (and Omega /
 // Omegas) a `fit` of the reference would have left in the struct's private fields.  `predict` then is
 // the reference's signature with its body replaced: validate -> one batched device call -> index ->
-// name.  Nothing in this header computes a distance on the CPU; without libvqhip.so and a gfx950
-// device every hot call throws.
+// name.  No batched call in this header computes a distance on the CPU; without libvqhip.so and a gfx950
+// device every one of them throws.  (LGMLVQ's two single-sample `pub fn(&self)` searches stay host loops, as in the
+// reference: one sample is not a batch.)  `evaluate` is row f3 of SURVEY.md section 8: the fit loops' matched search
+// for a whole data set at once, prototypes held fixed.
 #ifndef VQ_MODELS_HPP
 #define VQ_MODELS_HPP
 
 #include <algorithm>
 #include <cstdint>
+#include <limits>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -209,6 +212,56 @@ protected:
         return labels;
     }
 
+public:
+    // ---- the fit loops' matched search for a whole data set at once ----------------------
+    // For every sample: the nearest prototype of its own class (j_plus, d_plus) and the nearest of any other class
+    // (j_minus, d_minus) -- the two find_closest_prototype_matched calls and the two re-measured distances of
+    // src/glvq/glvq.rs:171-184 (gmlvq.rs / liramlvq.rs / lgmlvq.rs:194-199 with their Omega distances) -- plus what the
+    // reference derives from them per sample: the GLVQ cost term mu = (d+ - d-) / (d+ + d-) and the scalar factors of
+    // its two prototype updates, 4 d- / (d+ + d-)^2 and 4 d+ / (d+ + d-)^2 (glvq.rs:192-194).
+    // This is an EVALUATION with the prototypes held fixed (e.g. at the start of an epoch: cost, training error, the
+    // would-be update directions).  It is not `fit`: the reference updates its prototypes after every single sample
+    // (glvq.rs:204-205), which a batched call cannot reproduce and does not claim to.
+    struct Evaluation {
+        std::vector<uint32_t> j_plus, j_minus;
+        std::vector<double> d_plus, d_minus, mu, g_plus, g_minus;
+        double cost = 0.0;                             // sum of mu over the samples that have both prototypes
+        size_t misclassified = 0;                      // d- < d+  (mu > 0)
+    };
+    Evaluation evaluate(const Data &data, const std::vector<std::string> &labels)
+    {
+        check_predict_constraints(data);
+        rust_assert(data.size() == labels.size(), "The data vector does not match the label vector in length.");   // glvq.rs:70
+        upload();
+        const auto table = name_table();
+        std::vector<uint32_t> y(labels.size());
+        for (size_t i = 0; i < labels.size(); ++i) {
+            const auto it = table.find(labels[i]);
+            y[i] = it == table.end() ? 0xFFFFFFFFu : it->second;               // an unknown label matches no prototype
+        }
+        const std::vector<const double *> rows = row_pointers(data);
+        const size_t N = data.size();
+        Evaluation e;
+        e.j_plus.resize(N); e.j_minus.resize(N);
+        std::vector<float> dp(N), dn(N);
+        dev_->check(vqhip_assign_matched_rows_f64(dev_->get(), rows.data(), y.data(), N, (uint32_t)dim(), e.j_plus.data(), dp.data(),
+                                                  e.j_minus.data(), dn.data()));
+        e.d_plus.assign(dp.begin(), dp.end());
+        e.d_minus.assign(dn.begin(), dn.end());
+        e.mu.assign(N, 0.0); e.g_plus.assign(N, 0.0); e.g_minus.assign(N, 0.0);
+        for (size_t i = 0; i < N; ++i) {
+            const double d1 = e.d_plus[i], d2 = e.d_minus[i], s = d1 + d2;
+            if (!(s > 0.0) || !(s < 1e300)) continue;                         // no prototype of / outside the class, or both at distance 0
+            e.mu[i] = (d1 - d2) / s;
+            e.g_plus[i] = 4.0 * d2 / (s * s);
+            e.g_minus[i] = 4.0 * d1 / (s * s);
+            e.cost += e.mu[i];
+            e.misclassified += d2 < d1;
+        }
+        return e;
+    }
+
+protected:
     Data project_with(const Data &data, int which)
     {
         upload();
@@ -407,21 +460,38 @@ public:
     }
     Data project(const Data &data) { return project_with(data, VQHIP_PROJECT_LAMBDA); }  // :372-393
 
-    // The two `pub` single-sample searches (:436-455, :468-506).  The reference takes &self; here they
-    // go through the device like everything else, so they are not const.
-    size_t find_closest_local_prototype(const Vector &sample) { return closest(Data{sample})[0]; }
-    size_t find_closest_local_prototype_matched(const Vector &sample, const std::string &label, bool find_closest_matching)
+    // The two `pub` single-sample searches (:436-455, :468-506), `&self` in the reference and const here.  One sample
+    // is not a batch: a launch through pinned staging costs more than the K quadratic forms it would replace, so these
+    // stay on the host like the reference's helpers stay for `fit` -- the same loop, f64,
+    // Lambda_j = Omega_j^T Omega_j rebuilt per prototype as src/helpers.rs:38 does.  Batches go through predict / evaluate.
+    size_t find_closest_local_prototype(const Vector &sample) const { return host_search(sample, nullptr, true); }
+    size_t find_closest_local_prototype_matched(const Vector &sample, const std::string &label, bool find_closest_matching) const
     {
-        upload();
-        detail::rust_assert(sample.size() == dim(), "assertion failed: vec1.len() == vec2.len()");
-        const auto table = name_table();
-        const auto it = table.find(label);
-        const uint32_t y = it == table.end() ? 0xFFFFFFFFu : it->second;       // an unknown label matches nothing
-        std::vector<float> x(sample.begin(), sample.end());
-        uint32_t jpos = 0, jneg = 0;
-        dev_->check(vqhip_assign_matched(dev_->get(), x.data(), &y, 1, &jpos, nullptr, &jneg, nullptr));
-        return find_closest_matching ? jpos : jneg;
+        return host_search(sample, &label, find_closest_matching);
     }
+
+private:
+    size_t host_search(const Vector &sample, const std::string *label, bool matching) const
+    {
+        detail::rust_assert(sample.size() == dim(), "assertion failed: vec1.len() == vec2.len()");
+        size_t best = 0;
+        double smallest = std::numeric_limits<double>::infinity();               // lgmlvq.rs:439-440
+        for (size_t j = 0; j < prototypes_.size(); ++j) {
+            Vector diff(sample.size());
+            for (size_t d = 0; d < diff.size(); ++d) diff[d] = sample[d] - prototypes_[j].vector[d];   // helpers.rs:41
+            const Vector ld = omegas_[j].gram().dot(diff);                                             // helpers.rs:38, :44
+            double dist = 0.0;
+            for (size_t d = 0; d < diff.size(); ++d) dist += diff[d] * ld[d];
+            const bool eligible = !label || (prototypes_[j].name == *label) == matching;               // lgmlvq.rs:487 / :496
+            if (dist < smallest && eligible) {                                                         // strict '<': lgmlvq.rs:448
+                smallest = dist;
+                best = j;
+            }
+        }
+        return best;
+    }
+
+public:
 };
 
 #undef VQ_NOT_FIT

@@ -62,7 +62,7 @@ typedef enum {
 
 /* Creates a context on HIP device `device`.  Replaces nothing in the reference (it has no
  * device); it is what a Rust `Drop`-owning wrapper would hold inside the model struct. */
-int vqhip_create(int device, vqhip_ctx **out);
+int vqhip_create(int device, vqhip_ctx **out);   /* (several devices behind one handle: vqhip_multi_create below) */
 int vqhip_destroy(vqhip_ctx *ctx);
 
 /* Text of the last failure on this context ("" if none).  ctx == NULL: last vqhip_create failure. */
@@ -137,6 +137,33 @@ int vqhip_assign_matched(vqhip_ctx *ctx, const float *X, const uint32_t *y, uint
 int vqhip_assign_matched_device(vqhip_ctx *ctx, const float *dX, const uint32_t *dy, uint64_t N,
                                 uint32_t *djpos, float *ddpos, uint32_t *djneg, float *ddneg,
                                 void *stream);
+/* The same for the reference's own container (N separately allocated rows of D doubles, as vqhip_assign_rows_f64):
+ * what an evaluation of a whole data set at the start of an epoch passes in (src/glvq/glvq.rs:147-149, 171-184). */
+int vqhip_assign_matched_rows_f64(vqhip_ctx *ctx, const double *const *rows, const uint32_t *y, uint64_t N, uint32_t D,
+                                  uint32_t *jpos, float *dpos, uint32_t *jneg, float *dneg);
+
+/* ---- several GPUs of one node behind one handle (SURVEY.md section 8 rows b / e) ----------------------------------
+ * For a single-process caller (the Rust crate's `predict`, src/glvq/glvq.rs:217-235, whose samples are independent,
+ * :224-232): one context per listed device, the model replicated on each, the samples of a call cut into contiguous
+ * shards [g * ceil(N / n), (g + 1) * ceil(N / n)), one host thread per device driving that context's pinned upload
+ * pipeline, results written into the caller's arrays.  No exchange between the GPUs is needed for host-resident
+ * results.  (Device-resident shards, one process per GPU, with the RCCL all-gather of the results: vq_amd/dist.py,
+ * bench.py.)  A device may be listed more than once (two contexts on it).  Same semantics, status codes and
+ * threading contract (one caller at a time) as the single-device calls they forward to. */
+typedef struct vqhip_multi vqhip_multi; /* opaque */
+int vqhip_multi_create(const int *devices, int n_devices, vqhip_multi **out);
+int vqhip_multi_destroy(vqhip_multi *m);
+const char *vqhip_multi_last_error(const vqhip_multi *m);   /* m == NULL: last vqhip_multi_create failure */
+int vqhip_multi_device_count(const vqhip_multi *m);
+int vqhip_multi_set_prototypes(vqhip_multi *m, const float *W, uint32_t K, uint32_t D);
+int vqhip_multi_set_labels(vqhip_multi *m, const uint32_t *cls, uint32_t K);
+int vqhip_multi_set_omega(vqhip_multi *m, const float *Om, uint32_t M, uint32_t D);
+int vqhip_multi_set_local_omegas(vqhip_multi *m, const float *Oms, uint32_t K, uint32_t M, uint32_t D);
+int vqhip_multi_assign(vqhip_multi *m, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out);
+int vqhip_multi_assign_rows_f64(vqhip_multi *m, const double *const *rows, uint64_t N, uint32_t D, uint32_t *idx_out,
+                                float *dist_out);
+int vqhip_multi_assign_matched(vqhip_multi *m, const float *X, const uint32_t *y, uint64_t N, uint32_t *jpos,
+                               float *dpos, uint32_t *jneg, float *dneg);
 
 /* ---- projections ---------------------------------------------------------
  * project / project_omega for N samples.  X is N x D, row-major.

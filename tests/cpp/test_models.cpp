@@ -173,6 +173,30 @@ TEST(simple_classification_liramlvq)                                       // te
     CHECK(vec_all_close(model.prototypes()[0].vector, {0.6 * 0.6, -0.8 * 0.6}, 1e-12));
     CHECK(std::fabs(model.lambda()(0, 1) + 0.48) < 1e-12);
 }
+TEST(glvq_evaluate_matched_search_of_a_whole_set)                          // src/glvq/glvq.rs:171-194, prototypes held fixed
+{
+    GLVQ model = GLVQ::from_fitted(lvq_prototypes());
+    const Names labels = {"C0", "C0", "C1", "C1", "C1", "nope"};           // sample 2 is mislabelled, sample 5's label is unknown
+    const auto e = model.evaluate(TOY, labels);
+    CHECK((e.j_plus == std::vector<uint32_t>{0, 0, 1, 1, 1, 0}) && (e.j_minus == std::vector<uint32_t>{1, 1, 0, 0, 0, 1}));
+    // sample 0 = (5,2): d+ = 1 to C0 (5,3), d- = sqrt(100 + 81) to C1 (-5,11)
+    const double far0 = std::sqrt(181.0);
+    CHECK(std::fabs(e.d_plus[0] - 1.0) < 1e-6 && std::fabs(e.d_minus[0] - far0) < 1e-5);
+    CHECK(std::fabs(e.mu[0] - (1.0 - far0) / (1.0 + far0)) < 1e-6);
+    CHECK(std::fabs(e.g_plus[0] - 4.0 * far0 / ((1.0 + far0) * (1.0 + far0))) < 1e-6);      // glvq.rs:193
+    CHECK(std::fabs(e.g_minus[0] - 4.0 * 1.0 / ((1.0 + far0) * (1.0 + far0))) < 1e-6);      // glvq.rs:194
+    CHECK(e.d_plus[1] == 0.0 && std::fabs(e.mu[1] + 1.0) < 1e-12);          // (5,3) sits on its prototype: mu = -1
+    CHECK(e.mu[2] > 0.0 && e.misclassified == 1);                           // (5,4) labelled C1: nearer to the other class
+    CHECK(std::isinf(e.d_plus[5]) && e.mu[5] == 0.0);                       // no prototype carries "nope": index 0, +INF, left out
+    double want = 0.0;
+    for (size_t i = 0; i < 5; ++i) want += e.mu[i];
+    CHECK(std::fabs(e.cost - want) < 1e-12);
+    should_panic("The data vector does not match the label vector in length.", [&] { model.evaluate(TOY, {"C0"}); });
+    // with local Omegas the distances are the squared quadratic forms (src/lgmlvq/lgmlvq.rs:194-206)
+    LGMLVQ local = LGMLVQ::from_fitted(lvq_prototypes(), {identity_over_sqrt_n(2), identity_over_sqrt_n(2)});
+    const auto l = local.evaluate(TOY, {"C0", "C0", "C0", "C1", "C1", "C1"});
+    CHECK(std::fabs(l.d_plus[0] - 0.5) < 1e-6 && std::fabs(l.d_minus[0] - 90.5) < 1e-4 && l.misclassified == 0);
+}
 TEST(ties_go_to_the_first_prototype)                                       // src/helpers.rs:70
 {
     GLVQ model = GLVQ::from_fitted({{{1.0, 1.0}, "first"}, {{1.0, 1.0}, "second"}, {{9.0, 9.0}, "third"}});

@@ -81,3 +81,18 @@ def test_create_without_gpu_fails_loudly():
         Context(0)
     assert e.value.code in (_lib.ERR_HIP, _lib.ERR_UNSUPPORTED)
     assert "HIP device" in e.value.text or "gfx950" in e.value.text
+
+
+def test_host_side_builders_under_asan_and_ubsan():
+    """the host half of the model builder (duplicate detection, centring, every tile-image builder)
+    under -fsanitize=address,undefined, CPU only (`make asan` builds tests/cpp/test_host_asan with hipcc)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_host_asan")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", root, "asan"], check=True, timeout=900)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1"))
+    assert r.returncode == 0 and "host_asan_ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-4000:]

@@ -1,0 +1,110 @@
+"""GPU: the multi-device handle of the library (vqhip_multi_*), the pipelined host path of vqhip_project, and the matched
+search over separately allocated f64 rows -- the host-pointer entry points a single-process caller (the Rust crate) uses.
+A 1-GPU box lists device 0 twice: two contexts, two host threads, two shards."""
+import numpy as np
+import pytest
+
+import oracle
+import parity
+from vq_amd import KERNEL_AUTO, PROJECT_LAMBDA, PROJECT_OMEGA, Context, MultiContext, VqhipError
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]], ids=lambda d: "x%d" % len(d))
+def test_multi_handle_shards_and_matches_the_single_context(devices):
+    rng = np.random.default_rng(len(devices))
+    D, K, N = 128, 256, 50_001                                         # shards of unequal length
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    cls = (np.arange(K) % 4).astype(np.uint32)
+    y = rng.integers(0, 4, size=N).astype(np.uint32)
+    one = Context(0)
+    m = MultiContext(devices)
+    try:
+        assert m.device_count == len(devices)
+        one.set_prototypes(W); one.set_labels(cls)
+        m.set_prototypes(W); m.set_labels(cls)
+        i1, d1 = one.assign(X)
+        i2, d2 = m.assign(X)
+        assert (i1 == i2).all() and (d1.view(np.uint32) == d2.view(np.uint32)).all()
+        rep = parity.compare(i2[:3000], d2[:3000], *oracle.assign(X[:3000], W, threads=8))
+        assert rep.ok, str(rep)
+        for a, b in zip(one.assign_matched(X, y), m.assign_matched(X, y)):
+            assert (a.view(np.uint32) == b.view(np.uint32)).all()
+        rows = [np.array(r, dtype=np.float64) for r in X[:5000]]
+        i3, d3 = m.assign_rows(rows)
+        assert (i3 == i1[:5000]).all() and (d3 == d1[:5000]).all()
+        # fewer samples than devices, and none
+        i4, _ = m.assign(X[:1])
+        assert i4.tolist() == [int(i1[0])]
+        assert m.assign(X[:0])[0].shape == (0,)
+        # Omega models replicate too
+        Om = (rng.uniform(-1, 1, size=(16, D)) / np.sqrt(16 * D / 3.0)).astype(np.float32)
+        one.set_omega(Om); m.set_omega(Om)
+        i5, d5 = one.assign(X[:9999]); i6, d6 = m.assign(X[:9999])
+        assert (i5 == i6).all() and (d5 == d6).all()
+        with pytest.raises(VqhipError) as e:                            # an error of one shard comes back with its device
+            m.set_omega(np.zeros((3, D + 1), dtype=np.float32))
+        assert e.value.code == -1 and "device 0" in e.value.text
+    finally:
+        m.close()
+        one.close()
+    with pytest.raises(VqhipError):
+        MultiContext([99])
+
+
+def test_project_host_path_is_pipelined_over_chunks():
+    """vqhip_project from host pointers: more rows than one pinned buffer holds (D = 8: 4M-row chunks), both projections."""
+    rng = np.random.default_rng(4)
+    D, M = 8, 3
+    N = (128 << 20) // (D * 4) * 2 + 777
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    ctx = Context(0)
+    try:
+        ctx.set_kernel_policy(KERNEL_AUTO)
+        ctx.set_prototypes(rng.uniform(-1, 1, size=(3, D)).astype(np.float32))
+        ctx.set_omega(Om)
+        Z = ctx.project(X, PROJECT_OMEGA)
+        Y = ctx.project(X, PROJECT_LAMBDA)
+        for lo in (0, N // 2 - 300, N - 1000):
+            want_z = oracle.project_omega(Om, X[lo:lo + 1000])
+            want_y = oracle.project_lambda(Om, X[lo:lo + 1000])
+            assert np.abs(Z[lo:lo + 1000] - want_z).max() <= 1e-5 * np.abs(want_z).max()
+            assert np.abs(Y[lo:lo + 1000] - want_y).max() <= 1e-5 * np.abs(want_y).max()
+    finally:
+        ctx.close()
+
+
+def test_matched_rows_f64_equals_contiguous_f32():
+    rng = np.random.default_rng(6)
+    D, K, N = 64, 70, 6000
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    cls = (np.arange(K) % 5).astype(np.uint32)
+    y = rng.integers(0, 5, size=N).astype(np.uint32)
+    ctx = Context(0)
+    try:
+        ctx.set_prototypes(W); ctx.set_labels(cls)
+        a = ctx.assign_matched(X, y)
+        b = ctx.assign_matched_rows([np.array(r, dtype=np.float64) for r in X], y)
+        for u, v in zip(a, b):
+            assert (u.view(np.uint32) == v.view(np.uint32)).all()
+    finally:
+        ctx.close()
+
+
+def test_misaligned_device_pointers_are_refused():
+    import torch
+
+    ctx = Context(0)
+    try:
+        ctx.set_prototypes(np.zeros((4, 8), dtype=np.float32))
+        raw = torch.zeros(8 * 16 + 1, dtype=torch.float32, device="cuda")
+        idx = torch.zeros(16, dtype=torch.int32, device="cuda")
+        import ctypes as C
+        rc = ctx._L.vqhip_assign_device(ctx._h, C.c_void_p(raw.data_ptr() + 2), 16, C.c_void_p(idx.data_ptr()), None, None)
+        assert rc == -1 and b"aligned" in ctx._L.vqhip_last_error(ctx._h)
+    finally:
+        ctx.close()

@@ -30,3 +30,14 @@ def test_models_program_passes_on_the_gpu():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-4000:]
+
+
+@pytest.mark.gpu
+def test_models_program_linked_against_the_static_archive_passes_on_the_gpu():
+    """north_star: "a hipcc-built static library linked from build.rs".  The same test program, linked by plain g++
+    against vq_amd/libvqhip.a + libamdhip64 (Makefile: tests/cpp/test_models_static), as a Rust build would link it."""
+    exe = BIN + "_static"
+    assert os.path.exists(exe), "run `make` first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-4000:]

@@ -6,4 +6,4 @@ This package is the ctypes handle over it plus the host-side mirror of the refer
 computing does not.
 """
 from ._lib import (KERNEL_AUTO, KERNEL_MFMA, KERNEL_SCALAR, LIB_PATH, PROJECT_LAMBDA, PROJECT_OMEGA, VqhipError)  # noqa: F401
-from .context import Context  # noqa: F401
+from .context import Context, MultiContext  # noqa: F401

@@ -35,8 +35,20 @@ SIGNATURES = {
     "vqhip_prepare": (C.c_int, [_v]),
     "vqhip_assign_device_noalloc": (C.c_int, [_v, _v, C.c_uint64, _v, _v, _v]),
     "vqhip_assign_matched": (C.c_int, [_v, _f, _u, C.c_uint64, _u, _f, _u, _f]),
+    "vqhip_assign_matched_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), _u, C.c_uint64, C.c_uint32, _u, _f, _u, _f]),
     "vqhip_assign_matched_device": (C.c_int, [_v, _v, _v, C.c_uint64, _v, _v, _v, _v, _v]),
     "vqhip_last_kernel": (C.c_char_p, [_v]),
+    "vqhip_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "vqhip_multi_destroy": (C.c_int, [_v]),
+    "vqhip_multi_last_error": (C.c_char_p, [_v]),
+    "vqhip_multi_device_count": (C.c_int, [_v]),
+    "vqhip_multi_set_prototypes": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32]),
+    "vqhip_multi_set_labels": (C.c_int, [_v, _u, C.c_uint32]),
+    "vqhip_multi_set_omega": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32]),
+    "vqhip_multi_set_local_omegas": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "vqhip_multi_assign": (C.c_int, [_v, _f, C.c_uint64, _u, _f]),
+    "vqhip_multi_assign_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), C.c_uint64, C.c_uint32, _u, _f]),
+    "vqhip_multi_assign_matched": (C.c_int, [_v, _f, _u, C.c_uint64, _u, _f, _u, _f]),
     "vqhip_synth_fill_host": (C.c_int, [_f, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_float, _f, C.c_uint64]),
     "vqhip_synth_fill_device": (C.c_int, [_v, _v, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_float, _v,
                                           C.c_uint64, _v]),

@@ -178,6 +178,22 @@ class Context:
         self._chk(self._L.vqhip_assign_matched(self._h, _fp(X), _up(y), N, _up(jp), _fp(dp), _up(jn), _fp(dn)))
         return jp, dp, jn, dn
 
+    def assign_matched_rows(self, rows, y):
+        """The matched search for the reference's own container (separately allocated f64 rows)."""
+        rows = [np.ascontiguousarray(r, dtype=np.float64) for r in rows]
+        N = len(rows)
+        for r in rows:
+            if r.ndim != 1 or r.shape[0] != self.D:
+                raise ValueError(f"every row must hold {self.D} values")
+        y = np.ascontiguousarray(y, dtype=np.uint32)
+        if y.shape != (N,):
+            raise ValueError("y must have one class id per sample")
+        ptrs = (C.POINTER(C.c_double) * max(N, 1))(*[r.ctypes.data_as(C.POINTER(C.c_double)) for r in rows])
+        jp, jn = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.uint32)
+        dp, dn = np.empty(N, dtype=np.float32), np.empty(N, dtype=np.float32)
+        self._chk(self._L.vqhip_assign_matched_rows_f64(self._h, ptrs, _up(y), N, self.D, _up(jp), _fp(dp), _up(jn), _fp(dn)))
+        return jp, dp, jn, dn
+
     def assign_into(self, X, idx_out, dist_out=None, y=None, jneg_out=None, dneg_out=None):
         """Device path with caller-provided torch output tensors (int32 storage for indices)."""
         import torch
@@ -270,3 +286,82 @@ class Context:
         if X.device.index != self.device:
             raise ValueError(f"X lives on cuda:{X.device.index}, the context on cuda:{self.device}")
         self._check_shape(tuple(X.shape))
+
+
+class MultiContext:
+    """Several GPUs of one node behind one handle (vqhip_multi_*): the model replicated, the samples of a call cut into
+    contiguous shards, one host thread per device, results in the caller's arrays.  numpy in, numpy out."""
+
+    def __init__(self, devices):
+        self._L = _lib.lib()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._L.vqhip_multi_create(devs, len(devices), C.byref(h))
+        if rc != 0:
+            raise VqhipError(rc, self._L.vqhip_multi_last_error(None).decode())
+        self._h = h
+        self.D = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vqhip_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VqhipError(rc, self._L.vqhip_multi_last_error(self._h).decode())
+
+    @property
+    def device_count(self):
+        return self._L.vqhip_multi_device_count(self._h)
+
+    def set_prototypes(self, W):
+        W = np.ascontiguousarray(W, dtype=np.float32)
+        self._chk(self._L.vqhip_multi_set_prototypes(self._h, _fp(W), W.shape[0], W.shape[1]))
+        self.D = W.shape[1]
+
+    def set_labels(self, cls):
+        cls = np.ascontiguousarray(cls, dtype=np.uint32)
+        self._chk(self._L.vqhip_multi_set_labels(self._h, _up(cls), cls.shape[0]))
+
+    def set_omega(self, om):
+        om = np.ascontiguousarray(om, dtype=np.float32)
+        self._chk(self._L.vqhip_multi_set_omega(self._h, _fp(om), om.shape[0], om.shape[1]))
+
+    def set_local_omegas(self, om):
+        om = np.ascontiguousarray(om, dtype=np.float32)
+        self._chk(self._L.vqhip_multi_set_local_omegas(self._h, _fp(om), om.shape[0], om.shape[1], om.shape[2]))
+
+    def assign(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        if X.ndim != 2 or X.shape[1] != self.D:
+            raise ValueError(f"X must be N x {self.D}")
+        idx, dist = np.empty(X.shape[0], dtype=np.uint32), np.empty(X.shape[0], dtype=np.float32)
+        self._chk(self._L.vqhip_multi_assign(self._h, _fp(X), X.shape[0], _up(idx), _fp(dist)))
+        return idx, dist
+
+    def assign_rows(self, rows):
+        rows = [np.ascontiguousarray(r, dtype=np.float64) for r in rows]
+        for r in rows:
+            if r.ndim != 1 or r.shape[0] != self.D:
+                raise ValueError(f"every row must hold {self.D} values")
+        N = len(rows)
+        ptrs = (C.POINTER(C.c_double) * max(N, 1))(*[r.ctypes.data_as(C.POINTER(C.c_double)) for r in rows])
+        idx, dist = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.float32)
+        self._chk(self._L.vqhip_multi_assign_rows_f64(self._h, ptrs, N, self.D, _up(idx), _fp(dist)))
+        return idx, dist
+
+    def assign_matched(self, X, y):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.uint32)
+        N = X.shape[0]
+        jp, jn = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.uint32)
+        dp, dn = np.empty(N, dtype=np.float32), np.empty(N, dtype=np.float32)
+        self._chk(self._L.vqhip_multi_assign_matched(self._h, _fp(X), _up(y), N, _up(jp), _fp(dp), _up(jn), _fp(dn)))
+        return jp, dp, jn, dn

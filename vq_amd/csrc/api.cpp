@@ -53,6 +53,8 @@ struct Staging {                 // one of the two halves of the host-path pipel
     uint32_t *hY = nullptr;  uint32_t *dY = nullptr;       // sample class ids (matched)
     uint32_t *hI[2] = {nullptr, nullptr};  uint32_t *dI[2] = {nullptr, nullptr};
     float *hD[2] = {nullptr, nullptr};     float *dD[2] = {nullptr, nullptr};
+    float *hP = nullptr;     float *dP = nullptr;          // projected rows (vqhip_project), p_cap floats each
+    size_t p_cap = 0;
 };
 }  // namespace
 
@@ -105,6 +107,12 @@ struct vqhip_ctx {
     size_t st_chunk = 0;       // samples per staging buffer
     uint32_t st_D = 0;
 
+    // device buffers of the f64 entry points (one chunk of rows and its results), kept between calls
+    double *f64_dX = nullptr, *f64_dD[2] = {nullptr, nullptr};
+    uint32_t *f64_dY = nullptr, *f64_dI[2] = {nullptr, nullptr};
+    uint64_t f64_rows = 0;
+    uint32_t f64_D = 0;
+
     int fail(int code, const std::string &msg)
     {
         err = msg;
@@ -117,11 +125,38 @@ struct vqhip_ctx {
     }
 };
 
+// Nothing may unwind across the C ABI (include/vqhip.h): every extern "C" body is a function-try-block that ends in
+// VQHIP_CATCH.  bad_alloc -> VQHIP_ERR_NOMEM, anything else (std::system_error from a thread that would not start,
+// length_error, ...) -> VQHIP_ERR_INVALID, the text in vqhip_last_error.
+static int on_exception(vqhip_ctx *c) noexcept;
+#define VQHIP_CATCH(ctx) \
+    catch (...) { return on_exception(ctx); }
+
 #define HIPCHK(ctx, call)                                   \
     do {                                                    \
         hipError_t e_ = (call);                             \
         if (e_ != hipSuccess) return (ctx)->fail_hip(e_, #call); \
     } while (0)
+
+static int on_exception(vqhip_ctx *c) noexcept
+{
+    int code = VQHIP_ERR_INVALID;
+    char text[256] = "unknown C++ exception";
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = VQHIP_ERR_NOMEM;
+        std::snprintf(text, sizeof text, "out of host memory");
+    } catch (const std::exception &e) {
+        std::snprintf(text, sizeof text, "%s", e.what());
+    } catch (...) {
+    }
+    try {
+        (c ? c->err : g_create_error) = std::string("internal error: ") + text;
+    } catch (...) {                                       // not even the message fits: the code still tells
+    }
+    return code;
+}
 
 namespace {
 
@@ -155,6 +190,7 @@ void free_staging(vqhip_ctx *c)
             (void)hipHostFree(s.hI[j]); (void)hipFree(s.dI[j]);
             (void)hipHostFree(s.hD[j]); (void)hipFree(s.dD[j]);
         }
+        (void)hipHostFree(s.hP); (void)hipFree(s.dP);
         hipStream_t keep = s.stream;
         s = Staging();
         s.stream = keep;
@@ -248,6 +284,9 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
     if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
     if (dy && c->hcls.empty()) return c->fail(VQHIP_ERR_STATE, "matched search needs vqhip_set_labels");
     if (N == 0) return VQHIP_OK;
+    // the kernels fetch rows through 4-byte aligned buffer descriptors and store 4-byte results
+    if (((uintptr_t)dX | (uintptr_t)dy | (uintptr_t)out.idx | (uintptr_t)out.dist | (uintptr_t)out.jneg | (uintptr_t)out.dneg) & 3)
+        return c->fail(VQHIP_ERR_INVALID, "device pointers must be 4-byte aligned");
     int rc = prepare_engine(c);
     if (rc != VQHIP_OK) return rc;
 
@@ -340,9 +379,18 @@ void parallel_rows(uint64_t n, const std::function<void(uint64_t, uint64_t)> &fn
     }
     const uint64_t per = (n + workers - 1) / workers;
     std::vector<std::thread> pool;
-    for (unsigned w = 1; w < workers; ++w)
-        if (w * per < n) pool.emplace_back(fn, w * per, std::min<uint64_t>(n, (w + 1) * per));
-    fn(0, std::min<uint64_t>(n, per));
+    pool.reserve(workers);                                // (may throw before any thread exists)
+    uint64_t inline_from = n;                             // slices a thread could not be started for run here
+    for (unsigned w = 1; w < workers && w * per < n; ++w) {
+        try {
+            pool.emplace_back(fn, w * per, std::min<uint64_t>(n, (w + 1) * per));
+        } catch (...) {                                   // std::system_error: out of threads
+            inline_from = w * per;
+            break;
+        }
+    }
+    fn(0, std::min<uint64_t>(n, per));                    // the slices' bodies are memcpy / narrowing loops: they do not throw
+    if (inline_from < n) fn(inline_from, n);
     for (std::thread &t : pool) t.join();
 }
 
@@ -560,7 +608,33 @@ Packer contiguous_f32(const vqhip_ctx *c, const float *X)
     };
 }
 
-// f64 Euclidean path (row f4): plain chunked copies, the scalar kernel instantiated for double.
+void free_f64(vqhip_ctx *c)
+{
+    (void)hipFree(c->f64_dX); (void)hipFree(c->f64_dY);
+    for (int j = 0; j < 2; ++j) { (void)hipFree(c->f64_dD[j]); (void)hipFree(c->f64_dI[j]); }
+    c->f64_dX = nullptr; c->f64_dY = nullptr;
+    c->f64_dD[0] = c->f64_dD[1] = nullptr;
+    c->f64_dI[0] = c->f64_dI[1] = nullptr;
+    c->f64_rows = 0;
+    c->f64_D = 0;
+}
+
+// Vec<Array1<f64>> -> pinned contiguous f32, gathered and narrowed in one pass by the host cores
+Packer rows_f64(const double *const *rows, uint32_t D)
+{
+    return [rows, D](float *dst, uint64_t first, uint64_t n) {
+        parallel_rows(n, [=](uint64_t a, uint64_t b) {
+            for (uint64_t i = a; i < b; ++i) {
+                const double *src = rows[first + i];
+                float *out = dst + i * D;
+                for (uint32_t d = 0; d < D; ++d) out[d] = (float)src[d];
+            }
+        });
+    };
+}
+
+// f64 Euclidean path (row f4): plain chunked copies, the scalar kernel instantiated for double.  The chunk buffers
+// stay with the context between calls.
 int run_host_f64(vqhip_ctx *c, const double *X, const uint32_t *y, uint64_t N, uint32_t *o0, double *d0, uint32_t *o1,
                  double *d1)
 {
@@ -569,42 +643,77 @@ int run_host_f64(vqhip_ctx *c, const double *X, const uint32_t *y, uint64_t N, u
     if (N == 0) return VQHIP_OK;
     const uint32_t D = c->D;
     const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1024, (64ull << 20) / (D * sizeof(double))));
-    double *dX = nullptr, *dD[2] = {nullptr, nullptr};
-    uint32_t *dY = nullptr, *dI[2] = {nullptr, nullptr};
-    int rc = VQHIP_OK;
-    auto cleanup = [&]() {
-        (void)hipFree(dX); (void)hipFree(dY);
-        for (int j = 0; j < 2; ++j) { (void)hipFree(dD[j]); (void)hipFree(dI[j]); }
-    };
-#define F64CHK(call)                                  \
-    do {                                              \
-        hipError_t e_ = (call);                       \
-        if (e_ != hipSuccess) {                       \
-            rc = c->fail_hip(e_, #call);              \
-            cleanup();                                \
-            return rc;                                \
-        }                                             \
-    } while (0)
-    F64CHK(hipMalloc((void **)&dX, chunk * D * sizeof(double)));
-    F64CHK(hipMalloc((void **)&dY, chunk * sizeof(uint32_t)));
-    for (int j = 0; j < 2; ++j) {
-        F64CHK(hipMalloc((void **)&dD[j], chunk * sizeof(double)));
-        F64CHK(hipMalloc((void **)&dI[j], chunk * sizeof(uint32_t)));
+    if (c->f64_rows < chunk || c->f64_D != D) {
+        free_f64(c);
+        HIPCHK(c, hipMalloc((void **)&c->f64_dX, chunk * D * sizeof(double)));
+        HIPCHK(c, hipMalloc((void **)&c->f64_dY, chunk * sizeof(uint32_t)));
+        for (int j = 0; j < 2; ++j) {
+            HIPCHK(c, hipMalloc((void **)&c->f64_dD[j], chunk * sizeof(double)));
+            HIPCHK(c, hipMalloc((void **)&c->f64_dI[j], chunk * sizeof(uint32_t)));
+        }
+        c->f64_rows = chunk;
+        c->f64_D = D;
     }
+    double *dX = c->f64_dX, **dD = c->f64_dD;
+    uint32_t *dY = c->f64_dY, **dI = c->f64_dI;
     for (uint64_t off = 0; off < N; off += chunk) {
         const uint64_t n = std::min(chunk, N - off);
-        F64CHK(hipMemcpy(dX, X + off * D, n * D * sizeof(double), hipMemcpyHostToDevice));
-        if (y) F64CHK(hipMemcpy(dY, y + off, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(dX, X + off * D, n * D * sizeof(double), hipMemcpyHostToDevice));
+        if (y) HIPCHK(c, hipMemcpy(dY, y + off, n * sizeof(uint32_t), hipMemcpyHostToDevice));
         Outputs64 out{dI[0], dD[0], y ? dI[1] : nullptr, y ? dD[1] : nullptr};
-        F64CHK(launch_assign_scalar_f64(dX, n, D, c->dW64, c->K, c->dcls, y ? dY : nullptr, out, nullptr));
-        if (o0) F64CHK(hipMemcpy(o0 + off, dI[0], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        if (d0) F64CHK(hipMemcpy(d0 + off, dD[0], n * sizeof(double), hipMemcpyDeviceToHost));
-        if (y && o1) F64CHK(hipMemcpy(o1 + off, dI[1], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        if (y && d1) F64CHK(hipMemcpy(d1 + off, dD[1], n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(c, launch_assign_scalar_f64(dX, n, D, c->dW64, c->K, c->dcls, y ? dY : nullptr, out, nullptr));
+        if (o0) HIPCHK(c, hipMemcpy(o0 + off, dI[0], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (d0) HIPCHK(c, hipMemcpy(d0 + off, dD[0], n * sizeof(double), hipMemcpyDeviceToHost));
+        if (y && o1) HIPCHK(c, hipMemcpy(o1 + off, dI[1], n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (y && d1) HIPCHK(c, hipMemcpy(d1 + off, dD[1], n * sizeof(double), hipMemcpyDeviceToHost));
     }
-#undef F64CHK
-    cleanup();
     c->last_kernel = "scalar_f64";
+    return VQHIP_OK;
+}
+
+// project / project_omega from host pointers: the pinned, double-buffered pipeline of run_host (pack | H2D | kernel |
+// D2H | unpack on two streams), the projected rows in place of the winners.
+int run_host_project(vqhip_ctx *c, const float *X, uint64_t N, int which, float *Y)
+{
+    int rc = check_project(c, which);
+    if (rc != VQHIP_OK || N == 0) return rc;
+    const uint32_t D = c->D, Wd = project_width(c, which);
+    const size_t row = (size_t)D * sizeof(float);
+    size_t chunk = std::max<size_t>(1024, (128ull << 20) / (std::max(D, Wd) * sizeof(float)));
+    chunk = (size_t)std::min<uint64_t>(chunk, N);
+    if ((rc = ensure_staging(c, chunk, false)) != VQHIP_OK) return rc;
+    chunk = std::min<size_t>(c->st_chunk, (size_t)std::max<uint64_t>(1, std::min<uint64_t>(N, (128ull << 20) / (std::max(D, Wd) * sizeof(float)))));
+    for (Staging &s : c->st)
+        if (s.p_cap < chunk * Wd) {
+            HIPCHK(c, hipStreamSynchronize(s.stream));
+            (void)hipHostFree(s.hP); (void)hipFree(s.dP);
+            s.hP = nullptr; s.dP = nullptr; s.p_cap = 0;
+            HIPCHK(c, hipHostMalloc((void **)&s.hP, chunk * Wd * sizeof(float), hipHostMallocDefault));
+            HIPCHK(c, hipMalloc((void **)&s.dP, chunk * Wd * sizeof(float)));
+            s.p_cap = chunk * Wd;
+        }
+    const Packer pack = contiguous_f32(c, X);
+    const uint64_t nchunks = (N + chunk - 1) / chunk;
+    auto finish = [&](uint64_t ci) -> int {
+        Staging &s = c->st[ci & 1];
+        HIPCHK(c, hipStreamSynchronize(s.stream));
+        const uint64_t off = ci * chunk, n = std::min<uint64_t>(chunk, N - off);
+        const float *src = s.hP;
+        float *dst = Y + off * Wd;
+        parallel_rows(n, [=](uint64_t a, uint64_t b) { std::memcpy(dst + a * Wd, src + a * Wd, (b - a) * Wd * sizeof(float)); });
+        return VQHIP_OK;
+    };
+    for (uint64_t ci = 0; ci < nchunks; ++ci) {
+        Staging &s = c->st[ci & 1];
+        if (ci >= 2 && (rc = finish(ci - 2)) != VQHIP_OK) return rc;
+        const uint64_t off = ci * chunk, n = std::min<uint64_t>(chunk, N - off);
+        pack(s.hX, off, n);
+        HIPCHK(c, hipMemcpyAsync(s.dX, s.hX, n * row, hipMemcpyHostToDevice, s.stream));
+        if ((rc = project_device(c, s.dX, n, which, s.dP, s.stream)) != VQHIP_OK) return rc;
+        HIPCHK(c, hipMemcpyAsync(s.hP, s.dP, n * Wd * sizeof(float), hipMemcpyDeviceToHost, s.stream));
+    }
+    for (uint64_t ci = nchunks >= 2 ? nchunks - 2 : 0; ci < nchunks; ++ci)
+        if ((rc = finish(ci)) != VQHIP_OK) return rc;
     return VQHIP_OK;
 }
 
@@ -613,7 +722,7 @@ int run_host_f64(vqhip_ctx *c, const double *X, const uint32_t *y, uint64_t N, u
 extern "C" {
 
 int vqhip_create(int device, vqhip_ctx **out)
-{
+try {
     if (!out) {
         g_create_error = "out is NULL";
         return VQHIP_ERR_INVALID;
@@ -657,9 +766,10 @@ int vqhip_create(int device, vqhip_ctx **out)
     *out = c;
     return VQHIP_OK;
 }
+VQHIP_CATCH(nullptr)
 
 int vqhip_destroy(vqhip_ctx *c)
-{
+try {
     if (!c) return VQHIP_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
@@ -670,6 +780,7 @@ int vqhip_destroy(vqhip_ctx *c)
     free_omega(c);
     (void)hipFree(c->dW);
     (void)hipFree(c->dW64);
+    free_f64(c);
     (void)hipFree(c->dcls);
     (void)hipFree(c->dYproj);
     (void)hipFree(c->dProj);
@@ -677,6 +788,7 @@ int vqhip_destroy(vqhip_ctx *c)
     delete c;
     return VQHIP_OK;
 }
+VQHIP_CATCH(c)
 
 const char *vqhip_last_error(const vqhip_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
@@ -685,7 +797,7 @@ const char *vqhip_last_kernel(const vqhip_ctx *c) { return c ? c->last_kernel : 
 const char *vqhip_version(void) { return "vqhip 0.1 (gfx950)"; }
 
 int vqhip_set_prototypes(vqhip_ctx *c, const float *W, uint32_t K, uint32_t D)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (!W || K == 0 || D == 0) return c->fail(VQHIP_ERR_INVALID, "set_prototypes: W is NULL or K/D is 0");
     HIPCHK(c, hipSetDevice(c->device));
@@ -701,9 +813,10 @@ int vqhip_set_prototypes(vqhip_ctx *c, const float *W, uint32_t K, uint32_t D)
     c->D = D;
     return upload(c, &c->dW, W, (size_t)K * D);
 }
+VQHIP_CATCH(c)
 
 int vqhip_set_labels(vqhip_ctx *c, const uint32_t *cls, uint32_t K)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "set_labels before set_prototypes");
     if (!cls || K != c->K) return c->fail(VQHIP_ERR_INVALID, "set_labels: cls is NULL or K differs from the prototypes");
@@ -712,9 +825,10 @@ int vqhip_set_labels(vqhip_ctx *c, const uint32_t *cls, uint32_t K)
     c->hcls.assign(cls, cls + K);
     return upload(c, &c->dcls, cls, K);
 }
+VQHIP_CATCH(c)
 
 int vqhip_set_omega(vqhip_ctx *c, const float *Om, uint32_t M, uint32_t D)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "set_omega before set_prototypes");
     HIPCHK(c, hipSetDevice(c->device));
@@ -743,9 +857,10 @@ int vqhip_set_omega(vqhip_ctx *c, const float *Om, uint32_t M, uint32_t D)
         for (uint32_t d = 0; d < D; ++d) OmT[(size_t)d * M + m] = Om[(size_t)m * D + d];
     return upload(c, &c->dOmT, OmT.data(), OmT.size());
 }
+VQHIP_CATCH(c)
 
 int vqhip_set_local_omegas(vqhip_ctx *c, const float *Oms, uint32_t K, uint32_t M, uint32_t D)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "set_local_omegas before set_prototypes");
     HIPCHK(c, hipSetDevice(c->device));
@@ -759,64 +874,73 @@ int vqhip_set_local_omegas(vqhip_ctx *c, const float *Oms, uint32_t K, uint32_t 
     c->omega_kind = OMEGA_LOCAL;
     return upload(c, &c->dOm, Oms, (size_t)K * M * D);
 }
+VQHIP_CATCH(c)
 
 int vqhip_set_kernel_policy(vqhip_ctx *c, int policy)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (policy < VQHIP_KERNEL_AUTO || policy > VQHIP_KERNEL_MFMA) return c->fail(VQHIP_ERR_INVALID, "unknown kernel policy");
     c->policy = policy;
     return VQHIP_OK;
 }
+VQHIP_CATCH(c)
 
 int vqhip_assign(vqhip_ctx *c, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && !idx_out) return c->fail(VQHIP_ERR_INVALID, "assign: idx_out is NULL");
     if (N && !X) return c->fail(VQHIP_ERR_INVALID, "assign: X is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_host(c, contiguous_f32(c, X), nullptr, N, idx_out, dist_out, nullptr, nullptr);
 }
+VQHIP_CATCH(c)
 
 int vqhip_assign_rows_f64(vqhip_ctx *c, const double *const *rows, uint64_t N, uint32_t D, uint32_t *idx_out,
                           float *dist_out)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!rows || !idx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_rows_f64: rows or idx_out is NULL");
     if (c->K && D != c->D) return c->fail(VQHIP_ERR_INVALID, "assign_rows_f64: D differs from the prototypes");
     for (uint64_t i = 0; i < N; ++i)
         if (!rows[i]) return c->fail(VQHIP_ERR_INVALID, "assign_rows_f64: a row pointer is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    // Vec<Array1<f64>> -> pinned contiguous f32, gathered and narrowed in one pass by the host cores
-    const Packer pack = [rows, D](float *dst, uint64_t first, uint64_t n) {
-        parallel_rows(n, [=](uint64_t a, uint64_t b) {
-            for (uint64_t i = a; i < b; ++i) {
-                const double *src = rows[first + i];
-                float *out = dst + i * D;
-                for (uint32_t d = 0; d < D; ++d) out[d] = (float)src[d];
-            }
-        });
-    };
-    return run_host(c, pack, nullptr, N, idx_out, dist_out, nullptr, nullptr);
+    return run_host(c, rows_f64(rows, D), nullptr, N, idx_out, dist_out, nullptr, nullptr);
 }
+VQHIP_CATCH(c)
+
+int vqhip_assign_matched_rows_f64(vqhip_ctx *c, const double *const *rows, const uint32_t *y, uint64_t N, uint32_t D, uint32_t *jpos,
+                                  float *dpos, uint32_t *jneg, float *dneg)
+try {
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!rows || !y)) return c->fail(VQHIP_ERR_INVALID, "assign_matched_rows_f64: rows or y is NULL");
+    if (c->K && D != c->D) return c->fail(VQHIP_ERR_INVALID, "assign_matched_rows_f64: D differs from the prototypes");
+    for (uint64_t i = 0; i < N; ++i)
+        if (!rows[i]) return c->fail(VQHIP_ERR_INVALID, "assign_matched_rows_f64: a row pointer is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_host(c, rows_f64(rows, D), y, N, jpos, dpos, jneg, dneg);
+}
+VQHIP_CATCH(c)
 
 int vqhip_assign_device(vqhip_ctx *c, const float *dX, uint64_t N, uint32_t *didx_out, float *ddist_out, void *stream)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!dX || !didx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_device: dX or didx_out is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_device(c, dX, N, nullptr, Outputs{didx_out, ddist_out, nullptr, nullptr}, (hipStream_t)stream);
 }
+VQHIP_CATCH(c)
 
 int vqhip_prepare(vqhip_ctx *c)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
     HIPCHK(c, hipSetDevice(c->device));
     return prepare_engine(c);
 }
+VQHIP_CATCH(c)
 
 int vqhip_assign_device_noalloc(vqhip_ctx *c, const float *dX, uint64_t N, uint32_t *didx_out, float *ddist_out, void *stream)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N > VQHIP_NOALLOC_MAX_ROWS)
         return c->fail(VQHIP_ERR_INVALID, "assign_device_noalloc: N exceeds VQHIP_NOALLOC_MAX_ROWS (2^36 rows; the batch counters are 32-bit)");
@@ -837,59 +961,48 @@ int vqhip_assign_device_noalloc(vqhip_ctx *c, const float *dX, uint64_t N, uint3
                             c->noalloc_queue));
     return VQHIP_OK;
 }
+VQHIP_CATCH(c)
 
 int vqhip_assign_matched(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, uint32_t *jpos, float *dpos,
                          uint32_t *jneg, float *dneg)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!y || !X)) return c->fail(VQHIP_ERR_INVALID, "assign_matched: X or y is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_host(c, contiguous_f32(c, X), y, N, jpos, dpos, jneg, dneg);
 }
+VQHIP_CATCH(c)
 
 int vqhip_assign_matched_device(vqhip_ctx *c, const float *dX, const uint32_t *dy, uint64_t N, uint32_t *djpos,
                                 float *ddpos, uint32_t *djneg, float *ddneg, void *stream)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!dX || !dy)) return c->fail(VQHIP_ERR_INVALID, "assign_matched_device: dX or dy is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_device(c, dX, N, dy, Outputs{djpos, ddpos, djneg, ddneg}, (hipStream_t)stream);
 }
+VQHIP_CATCH(c)
 
 int vqhip_project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *dY, void *stream)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!dX || !dY)) return c->fail(VQHIP_ERR_INVALID, "project_device: dX or dY is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return project_device(c, dX, N, which, dY, (hipStream_t)stream);
 }
+VQHIP_CATCH(c)
 
 int vqhip_project(vqhip_ctx *c, const float *X, uint64_t N, int which, float *Y)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!X || !Y)) return c->fail(VQHIP_ERR_INVALID, "project: X or Y is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = check_project(c, which);
-    if (rc != VQHIP_OK || N == 0) return rc;
-    const uint32_t D = c->D, Wd = project_width(c, which);
-    const uint64_t chunk = std::min<uint64_t>(N, std::max<uint64_t>(1024, (64ull << 20) / (std::max(D, Wd) * 4ull)));
-    float *dX = nullptr, *dY = nullptr;
-    hipError_t e = hipMalloc((void **)&dX, chunk * D * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&dY, chunk * Wd * sizeof(float));
-    for (uint64_t off = 0; off < N && e == hipSuccess && rc == VQHIP_OK; off += chunk) {
-        const uint64_t n = std::min(chunk, N - off);
-        e = hipMemcpy(dX, X + off * D, n * D * sizeof(float), hipMemcpyHostToDevice);
-        if (e == hipSuccess) rc = project_device(c, dX, n, which, dY, nullptr);
-        if (e == hipSuccess && rc == VQHIP_OK) e = hipMemcpy(Y + off * Wd, dY, n * Wd * sizeof(float), hipMemcpyDeviceToHost);
-    }
-    (void)hipFree(dX);
-    (void)hipFree(dY);
-    if (e != hipSuccess) return c->fail_hip(e, "vqhip_project");
-    return rc;
+    return run_host_project(c, X, N, which, Y);
 }
+VQHIP_CATCH(c)
 
 int vqhip_set_prototypes_f64(vqhip_ctx *c, const double *W, uint32_t K, uint32_t D)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (!W || K == 0 || D == 0) return c->fail(VQHIP_ERR_INVALID, "set_prototypes_f64: W is NULL or K/D is 0");
     // the f32 model is set from the narrowed values, so both paths describe the same prototypes
@@ -899,32 +1012,225 @@ int vqhip_set_prototypes_f64(vqhip_ctx *c, const double *W, uint32_t K, uint32_t
     if (rc != VQHIP_OK) return rc;
     return upload(c, &c->dW64, W, (size_t)K * D);
 }
+VQHIP_CATCH(c)
 
 int vqhip_assign_f64(vqhip_ctx *c, const double *X, uint64_t N, uint32_t *idx_out, double *dist_out)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!X || !idx_out)) return c->fail(VQHIP_ERR_INVALID, "assign_f64: X or idx_out is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_host_f64(c, X, nullptr, N, idx_out, dist_out, nullptr, nullptr);
 }
+VQHIP_CATCH(c)
 
 int vqhip_assign_matched_f64(vqhip_ctx *c, const double *X, const uint32_t *y, uint64_t N, uint32_t *jpos, double *dpos,
                              uint32_t *jneg, double *dneg)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!X || !y)) return c->fail(VQHIP_ERR_INVALID, "assign_matched_f64: X or y is NULL");
     HIPCHK(c, hipSetDevice(c->device));
     return run_host_f64(c, X, y, N, jpos, dpos, jneg, dneg);
 }
+VQHIP_CATCH(c)
 
 int vqhip_synth_fill_device(vqhip_ctx *c, float *dout, uint64_t count, uint64_t first, uint64_t seed,
                             uint32_t stream_id, float scale, const float *dbase, uint64_t base_len, void *stream)
-{
+try {
     if (!c) return VQHIP_ERR_INVALID;
     if ((count && !dout) || (dbase && base_len == 0)) return c->fail(VQHIP_ERR_INVALID, "synth_fill_device: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, launch_synth_fill(dout, count, first, seed, stream_id, scale, dbase, base_len, (hipStream_t)stream));
     return VQHIP_OK;
 }
+VQHIP_CATCH(c)
+
+// ---- several GPUs behind one handle -------------------------------------------------------------------------------
+// One context per device, the model replicated, the samples of a call cut into contiguous shards
+// [g * ceil(N / n), (g + 1) * ceil(N / n)), one host thread per device driving its context's pinned pipeline, results
+// written straight into the caller's arrays (no exchange between the GPUs: every sample is independent,
+// src/glvq/glvq.rs:224-232).  The device-resident, one-process-per-GPU form with the RCCL gather is vq_amd/dist.py.
+}  // extern "C"
+
+struct vqhip_multi {
+    std::vector<vqhip_ctx *> ctx;
+    std::string err;
+    int fail(int code, const std::string &msg)
+    {
+        err = msg;
+        return code;
+    }
+};
+
+namespace {
+thread_local std::string g_multi_error;
+
+int on_exception_multi(vqhip_multi *m) noexcept
+{
+    int code = VQHIP_ERR_INVALID;
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = VQHIP_ERR_NOMEM;
+    } catch (...) {
+    }
+    try {
+        (m ? m->err : g_multi_error) = code == VQHIP_ERR_NOMEM ? "out of host memory" : "internal error (C++ exception)";
+    } catch (...) {
+    }
+    return code;
+}
+
+// fn(context, shard number) on every context, one host thread each; the first failure's code and text are kept
+int on_all(vqhip_multi *m, const std::function<int(vqhip_ctx *, size_t)> &fn, bool threads)
+{
+    const size_t n = m->ctx.size();
+    std::vector<int> rc(n, VQHIP_OK);
+    auto run = [&](size_t g) noexcept {
+        try {
+            rc[g] = fn(m->ctx[g], g);
+        } catch (...) {
+            rc[g] = on_exception(m->ctx[g]);
+        }
+    };
+    std::vector<std::thread> pool;
+    size_t started = 1;
+    if (threads && n > 1) {
+        pool.reserve(n);
+        for (; started < n; ++started) {
+            try {
+                pool.emplace_back(run, started);
+            } catch (...) {                               // no more threads: the rest runs on this one
+                break;
+            }
+        }
+    }
+    run(0);
+    for (size_t g = started; g < n; ++g) run(g);
+    for (std::thread &t : pool) t.join();
+    for (size_t g = 0; g < n; ++g)
+        if (rc[g] != VQHIP_OK)
+            return m->fail(rc[g], "device " + std::to_string(m->ctx[g]->device) + " (shard " + std::to_string(g) + "): " + m->ctx[g]->err);
+    return VQHIP_OK;
+}
+
+struct Shard {
+    uint64_t first, rows;
+};
+Shard shard_of(uint64_t N, size_t n, size_t g)
+{
+    const uint64_t per = (N + n - 1) / n, first = std::min<uint64_t>(N, g * per);
+    return {first, std::min<uint64_t>(per, N - first)};
+}
+}  // namespace
+
+#define VQHIP_CATCH_MULTI(mm) \
+    catch (...) { return on_exception_multi(mm); }
+
+extern "C" {
+
+int vqhip_multi_create(const int *devices, int n_devices, vqhip_multi **out)
+try {
+    if (!out) return VQHIP_ERR_INVALID;
+    *out = nullptr;
+    if (!devices || n_devices <= 0 || n_devices > MAX_DEVICES) {
+        g_multi_error = "multi_create: devices is NULL or n_devices out of range";
+        return VQHIP_ERR_INVALID;
+    }
+    vqhip_multi *m = new vqhip_multi();
+    for (int i = 0; i < n_devices; ++i) {
+        vqhip_ctx *c = nullptr;
+        const int rc = vqhip_create(devices[i], &c);
+        if (rc != VQHIP_OK) {
+            g_multi_error = "device " + std::to_string(devices[i]) + ": " + vqhip_last_error(nullptr);
+            for (vqhip_ctx *k : m->ctx) (void)vqhip_destroy(k);
+            delete m;
+            return rc;
+        }
+        m->ctx.push_back(c);
+    }
+    *out = m;
+    return VQHIP_OK;
+}
+VQHIP_CATCH_MULTI(nullptr)
+
+int vqhip_multi_destroy(vqhip_multi *m)
+try {
+    if (!m) return VQHIP_OK;
+    for (vqhip_ctx *c : m->ctx) (void)vqhip_destroy(c);
+    delete m;
+    return VQHIP_OK;
+}
+VQHIP_CATCH_MULTI(nullptr)
+
+const char *vqhip_multi_last_error(const vqhip_multi *m) { return m ? m->err.c_str() : g_multi_error.c_str(); }
+
+int vqhip_multi_device_count(const vqhip_multi *m) { return m ? (int)m->ctx.size() : 0; }
+
+int vqhip_multi_set_prototypes(vqhip_multi *m, const float *W, uint32_t K, uint32_t D)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    return on_all(m, [=](vqhip_ctx *c, size_t) { return vqhip_set_prototypes(c, W, K, D); }, false);
+}
+VQHIP_CATCH_MULTI(m)
+
+int vqhip_multi_set_labels(vqhip_multi *m, const uint32_t *cls, uint32_t K)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    return on_all(m, [=](vqhip_ctx *c, size_t) { return vqhip_set_labels(c, cls, K); }, false);
+}
+VQHIP_CATCH_MULTI(m)
+
+int vqhip_multi_set_omega(vqhip_multi *m, const float *Om, uint32_t M, uint32_t D)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    return on_all(m, [=](vqhip_ctx *c, size_t) { return vqhip_set_omega(c, Om, M, D); }, false);
+}
+VQHIP_CATCH_MULTI(m)
+
+int vqhip_multi_set_local_omegas(vqhip_multi *m, const float *Oms, uint32_t K, uint32_t M, uint32_t D)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    return on_all(m, [=](vqhip_ctx *c, size_t) { return vqhip_set_local_omegas(c, Oms, K, M, D); }, false);
+}
+VQHIP_CATCH_MULTI(m)
+
+int vqhip_multi_assign(vqhip_multi *m, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    if (N && (!X || !idx_out)) return m->fail(VQHIP_ERR_INVALID, "multi_assign: X or idx_out is NULL");
+    const size_t n = m->ctx.size();
+    return on_all(m, [=](vqhip_ctx *c, size_t g) {
+        const Shard sh = shard_of(N, n, g);
+        return vqhip_assign(c, X + sh.first * c->D, sh.rows, idx_out + sh.first, dist_out ? dist_out + sh.first : nullptr);
+    }, true);
+}
+VQHIP_CATCH_MULTI(m)
+
+int vqhip_multi_assign_rows_f64(vqhip_multi *m, const double *const *rows, uint64_t N, uint32_t D, uint32_t *idx_out,
+                                float *dist_out)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    if (N && (!rows || !idx_out)) return m->fail(VQHIP_ERR_INVALID, "multi_assign_rows_f64: rows or idx_out is NULL");
+    const size_t n = m->ctx.size();
+    return on_all(m, [=](vqhip_ctx *c, size_t g) {
+        const Shard sh = shard_of(N, n, g);
+        return vqhip_assign_rows_f64(c, rows + sh.first, sh.rows, D, idx_out + sh.first, dist_out ? dist_out + sh.first : nullptr);
+    }, true);
+}
+VQHIP_CATCH_MULTI(m)
+
+int vqhip_multi_assign_matched(vqhip_multi *m, const float *X, const uint32_t *y, uint64_t N, uint32_t *jpos, float *dpos,
+                               uint32_t *jneg, float *dneg)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    if (N && (!X || !y)) return m->fail(VQHIP_ERR_INVALID, "multi_assign_matched: X or y is NULL");
+    const size_t n = m->ctx.size();
+    return on_all(m, [=](vqhip_ctx *c, size_t g) {
+        const Shard sh = shard_of(N, n, g);
+        auto at = [&](auto *p) { return p ? p + sh.first : p; };
+        return vqhip_assign_matched(c, X + sh.first * c->D, y + sh.first, sh.rows, at(jpos), at(dpos), at(jneg), at(dneg));
+    }, true);
+}
+VQHIP_CATCH_MULTI(m)
 
 }  // extern "C"

@@ -404,10 +404,14 @@ bool bind_local_project(LocalProjectModel &m, std::vector<float> &pieces, const 
     const size_t per = (size_t)NT * NJ * 256;
     pieces.assign((size_t)m.K * per, 0.0f);
     const unsigned nthreads = std::max(1u, std::min(16u, std::min(m.K, std::thread::hardware_concurrency())));
+    // every allocation happens here, before a thread exists (an exception inside a thread ends the process); a worker
+    // that cannot be started has its share done by the caller
+    std::vector<std::vector<double>> lams(nthreads, std::vector<double>((size_t)D * D));
     std::vector<std::thread> pool;
-    for (unsigned w = 0; w < nthreads; ++w)
-        pool.emplace_back([&, w] {
-            std::vector<double> lam((size_t)D * D);
+    pool.reserve(nthreads);
+    auto work = [&](unsigned w) {
+        {
+            std::vector<double> &lam = lams[w];
             for (uint32_t k = w; k < m.K; k += nthreads) {
                 const float *om = &Oms[(size_t)k * M * D];
                 std::fill(lam.begin(), lam.end(), 0.0);
@@ -429,7 +433,18 @@ bool bind_local_project(LocalProjectModel &m, std::vector<float> &pieces, const 
                                 }
                         }
             }
-        });
+        }
+    };
+    unsigned started = 1;                                  // share 0 is the caller's
+    for (; started < nthreads; ++started) {
+        try {
+            pool.emplace_back(work, started);
+        } catch (...) {
+            break;
+        }
+    }
+    work(0);
+    for (unsigned w = started; w < nthreads; ++w) work(w);
     for (std::thread &t : pool) t.join();
     m.R = R;
     m.launch = &launch_project_local_t<R>;
