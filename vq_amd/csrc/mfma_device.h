@@ -146,16 +146,17 @@ struct BlockQueue {
     __device__ __forceinline__ BlockQueue(uint32_t *counters, int lane_, uint32_t wave_id, uint32_t nwaves, uint64_t nbatches)
         : ctr(counters), group(wave_id % QUEUE_GROUPS), first_dynamic(nwaves), pending(0u),
           nblocks((nbatches + BLOCK - 1) / BLOCK), lane(lane_) {}
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
     __device__ __forceinline__ void request()
     {
-        uint32_t fresh;                                // deliberately undefined off lane 0: no merge copy, so the
-        if (lane == 0)                                 // compiler's wait for the atomic lands at the first use
+        // Off lane 0 the value is never looked at (take() broadcasts lane 0), but it has to be SOMETHING: an empty asm
+        // defines it without an instruction.  Lane 0's atomic then overwrites its own lane of the same register, so no
+        // copy that would have to wait for the atomic's round trip sits between here and the first use.
+        uint32_t fresh;
+        asm volatile("" : "=v"(fresh));
+        if (lane == 0)
             fresh = __hip_atomic_fetch_add(ctr + group * QUEUE_GROUP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pending = fresh;
     }
-#pragma clang diagnostic pop
     __device__ __forceinline__ uint64_t block_of(uint32_t claim) const { return first_dynamic + (uint64_t)claim * QUEUE_GROUPS + group; }
     // First batch of the block claimed by the last request() (wave-uniform); >= nbatches when nothing is left.
     __device__ __forceinline__ uint64_t take()
