@@ -30,6 +30,7 @@ struct EngineModel {
     LaunchFn launch = nullptr;
     int samples_per_batch = 0;
     float ss_limit = 0.0f, wmax2 = 0.0f, mscale = 6.103515625e-05f;
+    bool bf = false;                  // k_resident_pipe: screening products on the bf16 matrix cores (mscale is then that path's)
 };
 
 namespace {
@@ -152,6 +153,13 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
             m.samples_per_batch = 32;
             m.launch = resident_cut_launcher(R1);
             m.name = "mfma_euclid_lds_pipe_cut";
+        }
+        // The pipelined kernels rank the prototypes on the bf16 matrix cores (search_tiles_bf, mfma_device.h): operands
+        // split into two bf16 pieces, three piece products.  Its margin: twice (3 * 2^-16 for the dropped parts + the f32
+        // accumulation of 3 R1 products + the key's 4 position bits), relative to ||x||^2 + max ||w||^2 like the f32 form's.
+        if (m.samples_per_batch == 32 && R1 <= 128 && variant_env() != 31 && variant_env() != 32 && !getenv("VQHIP_NO_BF")) {
+            m.bf = true;
+            m.mscale = (float)(6.0 / 65536.0 + 4.0 * (8.0 * std::sqrt(3.0 * R1) * 5.9604644775390625e-08 + 1.9073486328125e-06));
         }
     }
     return true;
@@ -575,6 +583,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.queue = queue ? queue : m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
     a.mu = m->mu;
     a.mscale = m->mscale;
+    a.bf = m->bf ? 1u : 0u;
     a.cls = m->cls;
     hipError_t e = m->launch(a, dy != nullptr, s);
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch

@@ -162,9 +162,15 @@ struct Staging {
 //
 // CUT: rows shorter than R (any length, 4-byte aligned; the image is zero padded): the 16-byte fetches are cut at
 // D in place once a set has landed (mask_chunk).
-template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false, bool CUT = false>
+//
+// BF: the screening products run on the bf16 matrix cores (search_tiles_bf, mfma_device.h).  The sample fragment is
+// split into bf16 pieces once per batch; the pieces die with the last tile, and without STAGED the next batch's rows
+// are requested into their registers right there (the f32 rows are still needed by the exact re-measurement):
+// two register sets that swap roles from batch to batch, the prefetch running over the epilogue and the partner wave.
+template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false, bool CUT = false, bool BF = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
 {
+    static_assert(!BF || R <= 128, "the bf16 pieces of a 256-value fragment do not fit beside the fragment");
     using Gm = Geom<R>;
     using St = Staging<R>;
     unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = 0;
@@ -253,7 +259,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             ln[q] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
         }
     };
-    if constexpr (SETS == 1) {
+    constexpr bool SWAP = BF && !STAGED;               // two sets, one batch in flight: see BF above
+    if constexpr (SETS == 1 || SWAP) {
         fetch(std::integral_constant<int, 0>{}, block0);
     } else {
         static_for<0, (int)BLOCK>([&](auto qq) { fetch(qq, block0 + decltype(qq)::value); });
@@ -316,7 +323,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
 
             Keys2 ku;
             KeysM km;
-            search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
+            if constexpr (BF) {
+                u32x4 bh[R / 16], bl[R / 16];
+                split_fragment<R>(xf, bh, bl);
+                search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km);
+            } else {
+                search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
+            }
+            if constexpr (SWAP) {                      // the pieces are dead: the next batch's rows take their registers
+                asm volatile("" ::: "memory");
+                fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
+            }
             lap(2);                                    // 2: tile loop
 
             Best1 wp, wn;
@@ -340,7 +357,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             if constexpr (SINGLE) {
                 asm volatile("" ::: "memory");
                 fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
-            } else if constexpr (!STAGED) {
+            } else if constexpr (!STAGED && !SWAP) {
                 asm volatile("" ::: "memory");
                 fetch(qq, nb0 + q);
             }
@@ -381,6 +398,10 @@ hipError_t launch_resident_staged(const EngineArgs &a, bool matched, hipStream_t
     if (e != hipSuccess) return e;
     if (R == 128 && a.dbg && !matched)                               // diagnostic build (VQHIP_VARIANT=32): phase stamps
         hipLaunchKernelGGL((k_resident_pipe<128, false, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    else if (a.bf && matched)
+        hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+    else if (a.bf)
+        hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, true, false, true>), dim3(grid), dim3(512), 0, st, a);
     else if (matched)
         hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
     else
@@ -395,6 +416,15 @@ hipError_t launch_resident_cut(const EngineArgs &a, bool matched, hipStream_t st
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
+    if constexpr (R <= 128) {
+        if (a.bf) {
+            if (matched)
+                hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, true, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, false, true, true>), dim3(grid), dim3(512), 0, st, a);
+            return hipGetLastError();
+        }
+    }
     if (matched)
         hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, true>), dim3(grid), dim3(512), 0, st, a);
     else
@@ -409,6 +439,15 @@ hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t s
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
+    if constexpr (R <= 128 && !DIAG) {
+        if (a.bf) {
+            if (matched)
+                hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, false, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, false, false, true>), dim3(grid), dim3(512), 0, st, a);
+            return hipGetLastError();
+        }
+    }
     if (DIAG && getenv("VQHIP_NW4"))
         hipLaunchKernelGGL((k_resident_pipe<R, false, true, 4>), dim3(grid), dim3(256), 0, st, a);
     else if (DIAG)

@@ -37,6 +37,7 @@ struct EngineArgs {
     float mscale;             // screening margin = mscale * (||x||^2 + wmax2): see screen_margin
     const float *mu;          // centre subtracted from every sample before anything else (R1 floats, zero padded), or null
     float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
+    uint32_t bf;              // resident_pipe: screening products on the bf16 matrix cores (search_tiles_bf); mscale is then its margin
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
     const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
@@ -707,6 +708,79 @@ __device__ __forceinline__ void search_tiles(const float *img, uint32_t ntiles, 
         last_screen<R, MATCHED>(acc0, tile, t, label, h, ku, km);
     } else {
         last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
+    }
+}
+
+// ------------------------------------------------------------------------------ the search on the bf16 matrix cores
+// Screening only ranks candidates: what leaves the kernel is re-measured in f32 in the direct form, and the third-key
+// guard (finish_keys) sends every sample the ranking could have got wrong to the exact scan.  So the ranking may run
+// wherever it is cheapest as long as its error is inside the margin -- and v_mfma_f32_32x32x16_bf16 does in 32 cycles
+// what sixteen v_mfma_f32_32x32x2_f32 do in 1 024, and leaves the vector ALUs free while it runs (the f32 form does
+// not: DESIGN.md 4.0).  Every f32 operand is split into two bf16 pieces, v = hi + lo + e with hi = bf16(v),
+// lo = bf16(v - hi), |e| <= 2^-16 |v| (round to nearest, 8 significant bits each), and three of the four piece
+// products are accumulated in f32: lo.hi + hi.lo + hi.hi.  The dropped parts (lo.lo, e.w, x.e) are below
+// 3 * 2^-16 |x_d| |a_d| per term, so a score differs from the f32-exact ||w||^2 - 2 x.w by less than
+// 3 * 2^-16 (||x||^2 + ||w||^2) plus the f32 accumulation: the host's margin for this path (engine_build, mscale_bf;
+// measured: tools/bf16x3_probe.hip).  The image in LDS stays the f32 one (the exact re-measurement reads it, and a
+// second image does not fit beside it at config 2's size), so the prototype fragments are split on the fly: 6 VALU
+// per pair of values, hidden under nothing -- this search is bound by the vector ALUs, at about a third of the f32
+// form's cycles per tile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float v0, float v1, uint32_t &hp, uint32_t &lp)
+{
+    hp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){v0, v1}, bf16x2));          // v_cvt_pk_bf16_f32
+    const float h0 = __builtin_bit_cast(float, hp << 16), h1 = __builtin_bit_cast(float, hp & 0xFFFF0000u);
+    lp = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){v0 - h0, v1 - h1}, bf16x2));
+}
+// the 8 values a lane contributes to one 32x32x16 step: its chunks 2q and 2q + 1 (any order, as long as both operands agree)
+__device__ __forceinline__ void split8(const f32x4 &a0, const f32x4 &a1, u32x4 &hi, u32x4 &lo)
+{
+    uint32_t h0, h1, h2, h3, l0, l1, l2, l3;
+    split2(a0[0], a0[1], h0, l0);
+    split2(a0[2], a0[3], h1, l1);
+    split2(a1[0], a1[1], h2, l2);
+    split2(a1[2], a1[3], h3, l3);
+    hi = u32x4{h0, h1, h2, h3};
+    lo = u32x4{l0, l1, l2, l3};
+}
+template <int R>
+__device__ __forceinline__ void split_fragment(const f32x4 (&xf)[R / 8], u32x4 (&bh)[R / 16], u32x4 (&bl)[R / 16])
+{
+#pragma unroll
+    for (int q = 0; q < R / 16; ++q) split8(xf[2 * q], xf[2 * q + 1], bh[q], bl[q]);
+}
+
+// search_tiles with the products on the bf16 matrix cores; same keys, same contract.
+template <int R, bool MATCHED>
+__device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntiles, uint32_t label, const u32x4 (&bh)[R / 16],
+                                                const u32x4 (&bl)[R / 16], int s_col, int h, Keys2 &ku, KeysM &km)
+{
+    using Gm = Geom<R>;
+    constexpr int NQ = R / 16;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(tile + Gm::W_FLOATS + 8 * g + 4 * h);
+            acc[4 * g + 0] = ci[0]; acc[4 * g + 1] = ci[1]; acc[4 * g + 2] = ci[2]; acc[4 * g + 3] = ci[3];
+        }
+        const float *rowp = tile + Gm::chunk_off(s_col, h);
+        static_for<0, NQ>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const f32x4 a0 = *(const f32x4 *)(rowp + 16 * q), a1 = *(const f32x4 *)(rowp + 16 * q + 8);
+            u32x4 ah, al;
+            split8(a0, a1, ah, al);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+        });
+        // the wait states between the last MFMA and the first read of its result, tied to the accumulator so that they stay there
+        asm volatile("s_nop 15\n\ts_nop 1" : "+v"(acc));
+        last_screen<R, MATCHED>(acc, tile, t, label, h, ku, km);
     }
 }
 
