@@ -120,6 +120,16 @@ int variant_env()
     return v ? atoi(v) : 0;
 }
 
+// The LDS-resident pipelined kernels rank the prototypes on the bf16 matrix cores (search_tiles_bf, mfma_device.h):
+// operands split into two bf16 pieces, three piece products.  Its margin: twice (3 * 2^-16 for the dropped parts + the
+// f32 accumulation of 3 R products + the key's 4 position bits), relative to ||x||^2 + max ||w||^2 like the f32 form's.
+void set_bf(EngineModel &m, int R)
+{
+    if (getenv("VQHIP_NO_BF")) return;
+    m.bf = true;
+    m.mscale = (float)(6.0 / 65536.0 + 4.0 * (8.0 * std::sqrt(3.0 * R) * 5.9604644775390625e-08 + 1.9073486328125e-06));
+}
+
 template <int R1>
 bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<float> &W, const std::vector<float> &norms,
                  const std::vector<uint32_t> &cls)
@@ -134,15 +144,16 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
             m.launch = resident_launcher(R1, &m.samples_per_batch);
             m.name = "mfma_euclid_lds";
         }
-        if (m.D == (uint32_t)R1 && pipe_ok && resident_pipe_launcher(R1, variant_env() == 31)) {   // unpadded rows: the pipelined kernel
+        const bool diag = variant_env() == 31 || variant_env() == 33;
+        if (m.D == (uint32_t)R1 && pipe_ok && resident_pipe_launcher(R1, diag)) {   // unpadded rows: the pipelined kernel
             m.samples_per_batch = 32;
-            m.launch = resident_pipe_launcher(R1, variant_env() == 31);
+            m.launch = resident_pipe_launcher(R1, diag);
             m.name = "mfma_euclid_lds_pipe";
             // few prototypes: the search is short, the memory pipe binds, rows are staged through LDS
             size_t staging = 0;
             const LaunchFn staged = resident_staged_launcher(R1, &staging);
             if (staged && res_tiles(m.K) <= 2 && (size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES + staging <= (size_t)RES_BYTES &&
-                variant_env() != 31 && !getenv("VQHIP_NO_STAGED")) {
+                !diag && !getenv("VQHIP_NO_STAGED")) {
                 m.launch = staged;
                 m.name = "mfma_euclid_lds_staged";
             }
@@ -154,13 +165,7 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
             m.launch = resident_cut_launcher(R1);
             m.name = "mfma_euclid_lds_pipe_cut";
         }
-        // The pipelined kernels rank the prototypes on the bf16 matrix cores (search_tiles_bf, mfma_device.h): operands
-        // split into two bf16 pieces, three piece products.  Its margin: twice (3 * 2^-16 for the dropped parts + the f32
-        // accumulation of 3 R1 products + the key's 4 position bits), relative to ||x||^2 + max ||w||^2 like the f32 form's.
-        if (m.samples_per_batch == 32 && R1 <= 128 && variant_env() != 31 && variant_env() != 32 && !getenv("VQHIP_NO_BF")) {
-            m.bf = true;
-            m.mscale = (float)(6.0 / 65536.0 + 4.0 * (8.0 * std::sqrt(3.0 * R1) * 5.9604644775390625e-08 + 1.9073486328125e-06));
-        }
+        if (m.samples_per_batch == 32 && R1 <= 128 && variant_env() != 31 && variant_env() != 32) set_bf(m, R1);
     }
     return true;
 }
@@ -304,6 +309,7 @@ bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &
     m.launch = lowrank_launcher(R1);
     m.samples_per_batch = 32;
     m.name = "mfma_omega_lowrank_lds";
+    set_bf(m, 16);
     return true;
 }
 
@@ -335,6 +341,7 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     m.launch = omega_pipe_launcher(R);
     m.samples_per_batch = 32;
     m.name = "mfma_omega_lds";
+    set_bf(m, R);
     return true;
 }
 
@@ -576,7 +583,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.wmax2 = m->wmax2;
     a.dbg = nullptr;
     static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
-    if ((variant_env() == 31 || variant_env() == 32) && !queue) {
+    if ((variant_env() == 31 || variant_env() == 32 || variant_env() == 33) && !queue) {
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
@@ -596,7 +603,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
             for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
         double tot = 0;
         for (int i = 0; i < 7; ++i) tot += sum[i];
-        if (variant_env() == 31 || variant_env() == 32) {
+        if (variant_env() == 31 || variant_env() == 32 || variant_env() == 33) {
             double s4[6] = {0};
             for (size_t w = 0; w < (size_t)256 * (getenv("VQHIP_NW4") ? 4 : 8); ++w)
                 for (int i = 0; i < 6; ++i) s4[i] += (double)h[w * 8 + i];

@@ -22,7 +22,7 @@ namespace vq {
 //     distance squared and not rooted (helpers.rs:44).
 // CUT (both kernels of this file): rows shorter than the padded length (any length, 4-byte aligned): the fetches are
 // cut at D in place before the projection reads them; the Omega images are zero there.
-template <int R1, bool MATCHED, bool CUT = false, int NW = 8>
+template <int R1, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineArgs a)
 {
     using Gs = Geom<16>;
@@ -167,7 +167,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         // ---- search in the projected space (k_resident_pipe's tile loop at R = 16)
         Keys2 ku;
         KeysM km;
-        search_tiles<16, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
+        if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above stays f32
+            u32x4 bh[1], bl[1];
+            split_fragment<16>(yf, bh, bl);
+            search_tiles_bf<16, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km);
+        } else {
+            search_tiles<16, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
+        }
 
         Best1 wp, wn;
         finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
 // ahead of its MFMAs.  No LDS stage, no barrier after the image load: waves run independently and
 // claim batches from the queue.  The projection's accumulators are the search stage's B fragment
 // (engine.h), the search is k_resident_pipe's, distance squared and not rooted (helpers.rs:44).
-template <int R, bool MATCHED, bool CUT = false, int NW = 8>
+template <int R, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs a)
 {
     using Gs = Geom<R>;
@@ -327,7 +333,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         // ---- search in the projected space (k_resident_pipe's tile loop)
         Keys2 ku;
         KeysM km;
-        search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
+        if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above stays f32
+            u32x4 bh[R / 16], bl[R / 16];
+            split_fragment<R>(yf, bh, bl);
+            search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km);
+        } else {
+            search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
+        }
 
         Best1 wp, wn;
         finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
@@ -359,7 +371,17 @@ hipError_t launch_lowrank(const EngineArgs &a, bool matched, hipStream_t st)
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    if (a.D < (uint32_t)R1) {
+    if (a.bf) {
+        if (a.D < (uint32_t)R1) {
+            if (matched)
+                hipLaunchKernelGGL((k_lowrank_pipe<R1, true, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_lowrank_pipe<R1, false, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
+        } else if (matched)
+            hipLaunchKernelGGL((k_lowrank_pipe<R1, true, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_lowrank_pipe<R1, false, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    } else if (a.D < (uint32_t)R1) {
         if (matched)
             hipLaunchKernelGGL((k_lowrank_pipe<R1, true, true>), dim3(grid), dim3(512), 0, st, a);
         else
@@ -378,7 +400,17 @@ hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    if (a.D < (uint32_t)R) {
+    if (a.bf) {
+        if (a.D < (uint32_t)R) {
+            if (matched)
+                hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_omega_pipe<R, false, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
+        } else if (matched)
+            hipLaunchKernelGGL((k_omega_pipe<R, true, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_omega_pipe<R, false, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    } else if (a.D < (uint32_t)R) {
         if (matched)
             hipLaunchKernelGGL((k_omega_pipe<R, true, true>), dim3(grid), dim3(512), 0, st, a);
         else

@@ -448,6 +448,12 @@ hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t s
             return hipGetLastError();
         }
     }
+    if constexpr (DIAG && R == 128) {
+        if (a.bf) {                                                   // VQHIP_VARIANT=33: phase stamps of the bf16 search
+            hipLaunchKernelGGL((k_resident_pipe<R, false, true, 8, false, false, true>), dim3(grid), dim3(512), 0, st, a);
+            return hipGetLastError();
+        }
+    }
     if (DIAG && getenv("VQHIP_NW4"))
         hipLaunchKernelGGL((k_resident_pipe<R, false, true, 4>), dim3(grid), dim3(256), 0, st, a);
     else if (DIAG)
