@@ -41,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: f32-input MFMA, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: bf16-input MFMA, dense (32 cycles per 32x32x16 on 1 024 SIMDs at 2.4 GHz)
 PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
 # device function behind each kernel family name reported by vqhip_last_kernel
 KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds_staged": "k_resident_pipe",
@@ -129,19 +130,42 @@ def bytes_per_sample(cfg):
     return cfg.D * 4 + 8                                      # sample row in, u32 index + f32 distance out
 
 
-def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=None):
+def matrix_work(cfg, ranking):
+    """Per sample: (flops the f32 matrix cores execute, flops the bf16 matrix cores execute).  With ranking "bf16x3" the
+    search products (2 K L of the algorithmic flops) run as three bf16 piece products each; projections stay f32."""
+    fl = flops_per_sample(cfg)
+    if ranking != "bf16x3":
+        return fl, 0
+    search = 2 * cfg.K * (cfg.D if cfg.omega == "none" else cfg.M)
+    return fl - search, 3 * search
+
+
+def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=None, ranking="f32"):
+    """achieved = ALGORITHMIC flops (or bytes) per launch / launch time.  MFMA peak = the same algorithmic flops over the
+    least time the matrix cores need for the instructions this kernel issues for them: f32 products at 157.3 TFLOP/s and,
+    where the candidates are ranked on the bf16 cores, three bf16 piece products per algorithmic product at 2 516.6
+    (so 838.9 algorithmic TFLOP/s for a pure search).  The f32-only peak is kept beside it for comparison."""
     fl, by = flops_per_sample(cfg), bytes_per_sample(cfg)
-    tflops = rows * fl / (launch_ms * 1e-3) / 1e12
-    gbs = rows * by / (launch_ms * 1e-3) / 1e9
-    blk = {"kernel": KERNEL_FN.get(kernel, "k_engine"), "launch_ms": launch_ms, "samples_per_launch": rows,
+    secs = launch_ms * 1e-3
+    tflops = rows * fl / secs / 1e12
+    gbs = rows * by / secs / 1e9
+    f32_fl, bf_fl = matrix_work(cfg, ranking)
+    t_min = f32_fl / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf_fl / (PEAK_BF16_MFMA_TFLOPS * 1e12)       # per sample
+    mfma_peak = fl / t_min / 1e12
+    blk = {"kernel": KERNEL_FN.get(kernel, "k_engine"), "ranking": ranking, "launch_ms": launch_ms, "samples_per_launch": rows,
            "flops_per_sample": fl, "bytes_per_sample": by, "traffic": traffic, "traffic_source": traffic_source,
            "tflops": tflops, "mfma_frac_of_157.3": tflops / PEAK_F32_MFMA_TFLOPS,
+           "f32_mfma_flops_per_sample": f32_fl, "bf16_mfma_flops_per_sample": bf_fl,
+           "f32_mfma_busy_frac": rows * f32_fl / (PEAK_F32_MFMA_TFLOPS * 1e12) / secs,
            "hbm_GBps_algorithmic": gbs, "hbm_frac_of_8TBps": gbs / PEAK_HBM_GBS}
     if cfg.name in HBM_BOUND:
         blk.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
     else:
-        blk.update({"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tflops / PEAK_F32_MFMA_TFLOPS})
+        blk.update({"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tflops / mfma_peak})
+        if ranking == "bf16x3":
+            blk["peak_note"] = ("algorithmic flops over the matrix cores' least time for this instruction mix: f32 MFMA at 157.3 TFLOP/s "
+                                "for projections, 3 bf16 piece products per search product at 2516.6; results are the f32 path's "
+                                "(exact f32 re-measurement + in-kernel guard)")
     return blk
 
 
@@ -416,7 +440,8 @@ def run_rank(args):
                 traffic, source = stored_traffic(args.workload)
                 if traffic is not None and why:
                     source += f" (live collection: {why})"
-            line["roofline"] = roofline_block(cfg, kernel, m_rows, launch_ms, traffic, source)
+            line["roofline"] = roofline_block(cfg, kernel, m_rows, launch_ms, traffic, source, ctx.last_ranking)
+            line["config"]["ranking"] = ctx.last_ranking
             if world == 1 and args.cpu_rows != 0:
                 line["cpu_baseline"] = cpu_baselines(cfg, model, sh.first_row(0), args.cpu_rows if args.cpu_rows > 0 else 0,
                                                      idx_loc[0].cpu().numpy(), budget_s=6.0)
@@ -425,10 +450,18 @@ def run_rank(args):
         del X, idx_buf, dst_buf
         torch.cuda.empty_cache()
         line["extra"] = {}
-        for name, xrows in (("c3", 10_000_000), ("c4", 10_000_000), ("c5", 4_000_000), ("c2k32", 10_000_000), ("c2k8", 10_000_000)):
-            xc = synth.CONFIGS[name]
+        # c2_f32 / c3_f32: the same workloads with the candidates ranked on the f32 matrix cores (VQHIP_NO_BF, read when the
+        # model's images are built): the kernels the f32-MFMA fractions of DESIGN.md section 5 are quoted on
+        for name, xrows in (("c3", 10_000_000), ("c4", 10_000_000), ("c5", 4_000_000), ("c2k32", 10_000_000), ("c2k8", 10_000_000),
+                            ("c2_f32", 10_000_000), ("c3_f32", 10_000_000)):
+            f32_only = name.endswith("_f32")
+            xc = synth.CONFIGS[name[:-4] if f32_only else name]
             xm = synth.make_model(xc)
+            if f32_only:
+                os.environ["VQHIP_NO_BF"] = "1"
             synth.load_model(ctx, xm)
+            ctx.prepare()
+            os.environ.pop("VQHIP_NO_BF", None)
             Xx = synth.samples_device(ctx, xm, 0, xrows)
             xi = torch.empty(xrows, dtype=torch.int32, device=dev)
             xd = torch.empty(xrows, dtype=torch.float32, device=dev)
@@ -447,12 +480,13 @@ def run_rank(args):
             torch.cuda.synchronize(dev)
             wall = time.perf_counter() - tw
             ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-            traffic, source = stored_traffic(name) if xrows == 10_000_000 else (None, None)
+            traffic, source = stored_traffic(name) if xrows == 10_000_000 and not f32_only else (None, None)
             entry = {"workload": f"{xc.model} predict, synthetic {xrows}x{xc.D} f32, {xc.K} prototypes"
                                  + (f", Omega {xc.M}x{xc.D} ({xc.omega})" if xc.omega != "none" else ""),
                      "value": xrows * n_launch / wall, "unit": "samples/s", "launches": n_launch, "ms_per_step": wall / n_launch * 1e3,
-                     "kernel": ctx.last_kernel, "roofline": roofline_block(xc, ctx.last_kernel, xrows, ms, traffic, source)}
-            if args.cpu_rows != 0:
+                     "kernel": ctx.last_kernel, "ranking": ctx.last_ranking,
+                     "roofline": roofline_block(xc, ctx.last_kernel, xrows, ms, traffic, source, ctx.last_ranking)}
+            if args.cpu_rows != 0 and not f32_only:
                 entry["cpu_baseline"] = cpu_baselines(xc, xm, 0, 0, xi.cpu().numpy(), budget_s=2.5)
             line["extra"][name] = entry
             del Xx, xi, xd

@@ -199,6 +199,13 @@ int vqhip_assign_matched_f64(vqhip_ctx *ctx, const double *X, const uint32_t *y,
  * "mfma_omega", "mfma_local", ...).  For tests and bench reports. */
 const char *vqhip_last_kernel(const vqhip_ctx *ctx);
 
+/* Where the last assign call ranked its candidates: "f32" (v_mfma_f32_32x32x2_f32), "bf16x3" (every f32 operand split
+ * into two bf16 pieces, three piece products on v_mfma_f32_32x32x16_bf16; the environment variable VQHIP_NO_BF turns
+ * it off) or "none" (kernels without a ranking stage: direct, local, scalar).  Ranking only picks the candidates: the
+ * winners and distances that come back are measured in f32 in the reference's direct form either way, and an in-kernel
+ * guard sends every sample whose ranking could be wrong to an exact scan, so both settings return the same results. */
+const char *vqhip_last_ranking(const vqhip_ctx *ctx);
+
 /* Counter-based synthetic data: value(seed, stream, i) in [-1, 1) as f32.
  * The host and device fills produce identical bits, so the CPU checker can regenerate any index
  * range of a device-resident matrix.  out[i] = base_scale * (base ? base[(first+i) % base_len] : 0)

@@ -1,0 +1,100 @@
+"""GPU: ranking the candidates on the bf16 matrix cores changes nothing that leaves the library.
+
+The LDS-resident kernels rank prototypes by ||w||^2 - 2 x.w with every f32 operand split into two bf16 pieces and three
+piece products on v_mfma_f32_32x32x16_bf16 (mfma_device.h search_tiles_bf); VQHIP_NO_BF (read when a model's images
+are built) keeps the ranking on v_mfma_f32_32x32x2_f32.  Either way the best two candidates are re-measured in f32 in
+the reference's direct form (src/helpers.rs:18-23) and a third key within the ranking's margin sends the sample to the
+exact in-order scan (src/helpers.rs:55-77), so winners AND distances must agree bit for bit between the two settings --
+on easy data, on dense clusters where the guard does the work, on wide-range data where the bf16 pieces are at their
+worst, plain and matched.  (Against the f64 oracle both are held to the usual bar by the other GPU tests, which run with
+the default, bf16 ranking.)"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+import parity
+from vq_amd import KERNEL_AUTO, Context
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(X, W, Om, cls, y, no_bf):
+    if no_bf:
+        os.environ["VQHIP_NO_BF"] = "1"
+    try:
+        ctx = Context(0)
+        ctx.set_kernel_policy(KERNEL_AUTO)
+        ctx.set_prototypes(W)
+        if Om is not None:
+            ctx.set_omega(Om)
+        idx, dist = ctx.assign(X)
+        out = {"kernel": ctx.last_kernel, "ranking": ctx.last_ranking, "idx": idx, "dist": dist}
+        ctx.set_labels(cls)
+        out["matched"] = ctx.assign_matched(X, y)
+        assert ctx.last_ranking == out["ranking"]
+        ctx.close()
+        return out
+    finally:
+        os.environ.pop("VQHIP_NO_BF", None)
+
+
+def _data(kind, rng, N, K, D):
+    if kind == "uniform":
+        return rng.uniform(-1, 1, size=(K, D)).astype(np.float32), rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    if kind == "wide":          # twelve binary orders of magnitude inside every row, signs mixed
+        W = (np.exp(rng.uniform(-4, 4, size=(K, D))) * rng.choice([-1.0, 1.0], size=(K, D))).astype(np.float32)
+        X = (np.exp(rng.uniform(-4, 4, size=(N, D))) * rng.choice([-1.0, 1.0], size=(N, D))).astype(np.float32)
+        return W, X
+    if kind == "dense":         # clusters of 4 prototypes 1e-3 ||w|| apart, samples 3e-3 ||w|| from a cluster
+        centres = rng.uniform(-1, 1, size=((K + 3) // 4, D))
+        W = np.repeat(centres, 4, axis=0)[:K]
+        u = rng.normal(size=(K, D))
+        W = (W + 1e-3 * np.linalg.norm(W, axis=1, keepdims=True) * u / np.linalg.norm(u, axis=1, keepdims=True)).astype(np.float32)
+        c = centres[rng.integers(0, len(centres), size=N)]
+        v = rng.normal(size=(N, D))
+        X = (c + 3e-3 * np.linalg.norm(c, axis=1, keepdims=True) * v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+        return W, X
+    if kind == "grid":          # integer features: exact ties between distinct prototypes, the lowest index wins
+        return rng.integers(0, 3, size=(K, D)).astype(np.float32), rng.integers(0, 3, size=(N, D)).astype(np.float32)
+    raise ValueError(kind)
+
+
+SHAPES = [
+    # name, D, K, M (0: Euclidean), kernel
+    ("glvq_c2", 128, 256, 0, "mfma_euclid_lds_pipe"),
+    ("lvq_k20_staged", 128, 20, 0, "mfma_euclid_lds_staged"),
+    ("glvq_d100_cut", 100, 37, 0, "mfma_euclid_lds_pipe_cut"),
+    ("glvq_d16", 16, 300, 0, "mfma_euclid_lds_pipe"),
+    ("gmlvq_c3", 128, 256, 128, "mfma_omega_lds"),
+    ("liramlvq_c4", 256, 1024, 16, "mfma_omega_lowrank_lds"),
+]
+
+
+@pytest.mark.parametrize("kind", ["uniform", "wide", "dense", "grid"])
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+def test_bf16_ranking_returns_the_f32_rankings_results(shape, kind):
+    name, D, K, M, kernel = shape
+    rng = np.random.default_rng(zlib.crc32(f"{name}-{kind}".encode()))
+    N = 4099
+    W, X = _data(kind, rng, N, K, D)
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32) if M else None
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    bf = _run(X, W, Om, cls, y, no_bf=False)
+    f32 = _run(X, W, Om, cls, y, no_bf=True)
+    assert bf["kernel"] == kernel and f32["kernel"] == kernel, (bf["kernel"], f32["kernel"])
+    assert bf["ranking"] == "bf16x3" and f32["ranking"] == "f32", (bf["ranking"], f32["ranking"])
+    assert np.array_equal(bf["idx"], f32["idx"]), f"{int((bf['idx'] != f32['idx']).sum())} winners differ"
+    assert np.array_equal(bf["dist"].view(np.uint32), f32["dist"].view(np.uint32)), "distances differ"
+    for a, b, what in zip(bf["matched"], f32["matched"], ("j+", "d+", "j-", "d-")):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32)), f"matched {what} differs"
+    # and the shared answer is the oracle's (a subset keeps the f64 oracle quick on the Omega shapes)
+    sel = slice(0, 400 if M else N)
+    rep = parity.compare(bf["idx"][sel], bf["dist"][sel], *oracle.assign(X[sel], W, omega=Om, threads=8), atol=2e-6 if M else 0.0)
+    print(name, kind, rep)
+    assert rep.ok, str(rep)
+    if kind == "grid" and not M:
+        assert rep.mismatches == 0, str(rep)

@@ -98,6 +98,11 @@ class Context:
     def last_kernel(self) -> str:
         return self._L.vqhip_last_kernel(self._h).decode()
 
+    @property
+    def last_ranking(self) -> str:
+        """Where the last assign call ranked its candidates: "f32", "bf16x3" or "none" (vqhip_last_ranking)."""
+        return self._L.vqhip_last_ranking(self._h).decode()
+
     # -- hot path
     def assign(self, X, want_dist: bool = True):
         """find_closest_prototype for every row of X -> (idx, dist).

@@ -62,6 +62,7 @@ struct vqhip_ctx {
     int device = 0;
     std::string err;
     const char *last_kernel = "none";
+    const char *last_ranking = "none";
     int policy = VQHIP_KERNEL_AUTO;
 
     uint32_t K = 0, D = 0, M = 0;
@@ -292,6 +293,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
 
     if (c->engine && c->policy != VQHIP_KERNEL_SCALAR) {      // (an engine built before the policy was set to scalar stays unused)
         c->last_kernel = engine_name(c->engine);
+        c->last_ranking = engine_ranking(c->engine);
         HIPCHK(c, engine_assign(c->engine, dX, N, dy, out, s));
         return VQHIP_OK;
     }
@@ -316,10 +318,12 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
             if (dy) HIPCHK(c, launch_square(o.dneg, n, s));
         }
         c->last_kernel = "mfma_omega_two_pass";
+        c->last_ranking = engine_ranking(c->engine2);
         return scratch_release(c, s);
     }
 
     c->last_kernel = "scalar";
+    c->last_ranking = "none";
     if (c->omega_kind == OMEGA_NONE) {
         HIPCHK(c, launch_assign_scalar(dX, N, c->D, c->dW, c->K, c->dcls, dy, /*rooted=*/true, out, s));
     } else if (c->omega_kind == OMEGA_GLOBAL) {
@@ -793,6 +797,7 @@ VQHIP_CATCH(c)
 const char *vqhip_last_error(const vqhip_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 const char *vqhip_last_kernel(const vqhip_ctx *c) { return c ? c->last_kernel : "none"; }
+const char *vqhip_last_ranking(const vqhip_ctx *c) { return c ? c->last_ranking : "none"; }
 
 const char *vqhip_version(void) { return "vqhip 0.1 (gfx950)"; }
 
@@ -956,6 +961,7 @@ try {
     HIPCHK(c, hipSetDevice(c->device));
     if (N == 0) return VQHIP_OK;
     c->last_kernel = engine_name(c->engine);
+    c->last_ranking = engine_ranking(c->engine);
     // c->noalloc_queue is the device address of `scratch` on this GPU (never the array's name); the launch zeroes it
     HIPCHK(c, engine_assign(c->engine, dX, N, nullptr, Outputs{didx_out, ddist_out, nullptr, nullptr}, (hipStream_t)stream,
                             c->noalloc_queue));

@@ -566,6 +566,11 @@ void engine_free(EngineModel *m)
 }
 
 const char *engine_name(const EngineModel *m) { return m->name; }
+const char *engine_ranking(const EngineModel *m)
+{
+    if (m->bf) return "bf16x3";
+    return m->mode == MODE_LOCAL || std::strncmp(m->name, "valu", 4) == 0 ? "none" : "f32";
+}
 
 hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s, uint32_t *queue)
 {
