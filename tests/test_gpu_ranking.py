@@ -70,6 +70,8 @@ SHAPES = [
     ("glvq_d16", 16, 300, 0, "mfma_euclid_lds_pipe"),
     ("gmlvq_c3", 128, 256, 128, "mfma_omega_lds"),
     ("liramlvq_c4", 256, 1024, 16, "mfma_omega_lowrank_lds"),
+    ("vq_k1024_streamed", 128, 1024, 0, "mfma_euclid"),
+    ("gmlvq_k600_streamed", 128, 600, 128, "mfma_omega"),
 ]
 
 

@@ -165,8 +165,10 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
             m.launch = resident_cut_launcher(R1);
             m.name = "mfma_euclid_lds_pipe_cut";
         }
-        if (m.samples_per_batch == 32 && R1 <= 128 && variant_env() != 31 && variant_env() != 32) set_bf(m, R1);
     }
+    // k_engine and the pipelined resident kernels rank on the bf16 matrix cores (k_resident, padded rows, does not)
+    const bool plain_diag = variant_env() == 31 || variant_env() == 32;
+    if (R1 <= 128 && std::strcmp(m.name, "mfma_euclid_lds") != 0 && !plain_diag) set_bf(m, R1);
     return true;
 }
 
@@ -276,6 +278,7 @@ bool bind_omega(EngineModel &m, std::vector<float> &img1, std::vector<float> &im
     img2 = build_images<R2>(P.data(), m.K, m.M, m.M, -2.0f, norms.data(), cls.empty() ? nullptr : cls.data(), PAD_SCORE,
                             m.ngroups2);
     m.launch = streamed_launcher(MODE_OMEGA, R1, R2, &m.samples_per_batch);
+    if (R2 <= 128) set_bf(m, R2);
     return true;
 }
 

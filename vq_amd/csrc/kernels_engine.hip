@@ -30,9 +30,11 @@ namespace vq {
 // projected, so the next batch's rows are fetched into the same registers while the search runs
 // (every workgroup of the chip loading, then computing, in lockstep is an HBM burst followed by HBM
 // silence).  The search stages screen with packed keys (4 VALU per score, see k_resident_pipe).
-template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS>
+// BF: the search stage's products on the bf16 matrix cores (tile_mma_bf, mfma_device.h); projections stay f32.
+template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, bool BF = false>
 __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
 {
+    static_assert(!BF || MODE != MODE_LOCAL, "LOCAL has no ranking stage");
     using G1 = Geom<R1>;
     using G2 = Geom<MODE == MODE_OMEGA ? R2 : R1>;
     constexpr int RS = MODE == MODE_OMEGA ? R2 : R1;                 // reduction length of the search stage
@@ -215,6 +217,11 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
             }
         }
 
+        u32x4 bh[BF ? S : 1][RS / 16], bl[BF ? S : 1][RS / 16];       // search fragments as bf16 pieces
+        if constexpr (BF) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) split_fragment<RS>(yf[s], bh[s], bl[s]);
+        }
         const uint32_t nsearch = MODE == MODE_OMEGA ? a.ngroups2 : a.ngroups1;
         for (uint32_t qs = 0; qs < nsearch; ++qs) {
             step([&](const float *stage) {
@@ -250,7 +257,8 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     for (int tt = 0; tt < G2::G; ++tt) {
                         const float *tile = stage + tt * G2::TILE_FLOATS;
                         f32x16 acc[S];
-                        tile_mma<RS, S>(tile, yf, acc, s_col, h);
+                        if constexpr (BF) tile_mma_bf<RS, S>(tile, bh, bl, acc, s_col, h);
+                        else tile_mma<RS, S>(tile, yf, acc, s_col, h);
                         const uint32_t tile_id = qs * G2::G + tt;
                         const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32 + 4 * h;
                         Keys2 ou[S];
@@ -269,7 +277,8 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                         } else {
                             // the keys are packed by inline asm, which the compiler does not count as a reader of
                             // the accumulators the MFMA right in front has written: wait states by hand
-                            asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
+#pragma unroll
+                            for (int s = 0; s < S; ++s) settle_mfma(acc[s]);
                             static_for<0, 16>([&](auto oo) {
                                 constexpr int o = decltype(oo)::value;
                                 const uint32_t cls = tcls[8 * (o >> 2) + (o & 3)];
@@ -354,6 +363,15 @@ hipError_t launch_t(const EngineArgs &a, bool matched, hipStream_t st)
     const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
+    if constexpr (MODE != MODE_LOCAL && (MODE == MODE_OMEGA ? R2 : R1) <= 128) {
+        if (a.bf) {
+            if (matched)
+                hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS, true>), dim3(grid), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false, WPS, true>), dim3(grid), dim3(256), 0, st, a);
+            return hipGetLastError();
+        }
+    }
     if (matched)
         hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS>), dim3(grid), dim3(256), 0, st, a);
     else

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
                 } else {
                     const KeysM before = km;
                     const uint32_t *tcls = (const uint32_t *)(gtails + t * TAIL_FLOATS) + 32 + 4 * h;
-                    asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");   // asm readers of fresh MFMA results: wait states by hand
+                    settle_mfma(acc[t]);                       // asm readers of fresh MFMA results: wait states by hand
                     static_for<0, 16>([&](auto oo) {
                         constexpr int o = decltype(oo)::value;
                         const uint32_t key = pack_key(acc[t][o], o);

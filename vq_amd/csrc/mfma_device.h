@@ -197,6 +197,10 @@ struct KeysM {                       // labelled search: best two keys with cls 
 };
 __device__ __forceinline__ bool key_valid(uint32_t key) { return __builtin_bit_cast(float, key) < KEY_VALID_F; }
 
+// Wait states between an MFMA that has just written `acc` and inline asm that reads it (the compiler pads hazards only
+// for instructions it knows): tied to the accumulator, so the statement stays behind the MFMA and in front of the readers.
+__device__ __forceinline__ void settle_mfma(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 1" : "+v"(acc)); }
+
 __device__ __forceinline__ uint32_t pack_key(float score, uint32_t o)
 {
     uint32_t key;                                   // (bits & ~15) | o in one instruction
@@ -230,76 +234,85 @@ __device__ __forceinline__ void offer_m(KeysM &km, uint32_t kp, uint32_t kn)
 // and the third best key (4 VALU per score).  One asm statement: the compiler pads a wait state behind every inline-asm result
 // that the next instruction reads, and the chain b1 -> b1 would collect one per score.  PRE_NOPS: wait
 // states for accumulators that the MFMA right in front of the statement has written.
+// The nops of the PRE_NOPS form are the wait states between an MFMA that has just written the scores and their first
+// reader, and they are part of the SAME asm statement as the readers: the compiler does not count inline asm as a
+// reader of MFMA results (no hazard padding of its own), and a separate nop statement is free to drift away from them.
+#define VQ_SCREEN16_TEXT \
+    "v_and_or_b32 %[t0], %[s0], %[m], 0\n\t" \
+    "v_and_or_b32 %[t1], %[s1], %[m], 1\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_and_or_b32 %[t0], %[s2], %[m], 2\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    "v_and_or_b32 %[t1], %[s3], %[m], 3\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_and_or_b32 %[t0], %[s4], %[m], 4\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    "v_and_or_b32 %[t1], %[s5], %[m], 5\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_and_or_b32 %[t0], %[s6], %[m], 6\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    "v_and_or_b32 %[t1], %[s7], %[m], 7\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_and_or_b32 %[t0], %[s8], %[m], 8\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    "v_and_or_b32 %[t1], %[s9], %[m], 9\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_and_or_b32 %[t0], %[s10], %[m], 10\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    "v_and_or_b32 %[t1], %[s11], %[m], 11\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_and_or_b32 %[t0], %[s12], %[m], 12\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    "v_and_or_b32 %[t1], %[s13], %[m], 13\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_and_or_b32 %[t0], %[s14], %[m], 14\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    "v_and_or_b32 %[t1], %[s15], %[m], 15\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t" \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t" \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t" \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t" \
+    ""
 template <int PRE_NOPS = 0>
 __device__ __forceinline__ void screen16(const f32x16 &sc, Keys2 &ku)
 {
     uint32_t t0, t1;
-    if constexpr (PRE_NOPS > 0) asm volatile("s_nop 15\n\ts_nop 1" ::: "memory");
-    asm(
-        "v_and_or_b32 %[t0], %[s0], %[m], 0\n\t"
-        "v_and_or_b32 %[t1], %[s1], %[m], 1\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_and_or_b32 %[t0], %[s2], %[m], 2\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        "v_and_or_b32 %[t1], %[s3], %[m], 3\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_and_or_b32 %[t0], %[s4], %[m], 4\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        "v_and_or_b32 %[t1], %[s5], %[m], 5\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_and_or_b32 %[t0], %[s6], %[m], 6\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        "v_and_or_b32 %[t1], %[s7], %[m], 7\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_and_or_b32 %[t0], %[s8], %[m], 8\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        "v_and_or_b32 %[t1], %[s9], %[m], 9\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_and_or_b32 %[t0], %[s10], %[m], 10\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        "v_and_or_b32 %[t1], %[s11], %[m], 11\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_and_or_b32 %[t0], %[s12], %[m], 12\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        "v_and_or_b32 %[t1], %[s13], %[m], 13\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_and_or_b32 %[t0], %[s14], %[m], 14\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
-        "v_and_or_b32 %[t1], %[s15], %[m], 15\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t0]\n\t"
-        "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"
-        "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"
-        "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+    if constexpr (PRE_NOPS > 0)
+        asm("s_nop 15\n\ts_nop 1\n\t" VQ_SCREEN16_TEXT
+        : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [b3] "+v"(ku.b3), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [s0] "v"(sc[0]), [s1] "v"(sc[1]), [s2] "v"(sc[2]), [s3] "v"(sc[3]), [s4] "v"(sc[4]), [s5] "v"(sc[5]), [s6] "v"(sc[6]), [s7] "v"(sc[7]), [s8] "v"(sc[8]), [s9] "v"(sc[9]), [s10] "v"(sc[10]), [s11] "v"(sc[11]), [s12] "v"(sc[12]), [s13] "v"(sc[13]), [s14] "v"(sc[14]), [s15] "v"(sc[15]), [m] "s"(0xFFFFFFF0u));
+    else
+        asm(VQ_SCREEN16_TEXT
         : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [b3] "+v"(ku.b3), [t0] "=&v"(t0), [t1] "=&v"(t1)
         : [s0] "v"(sc[0]), [s1] "v"(sc[1]), [s2] "v"(sc[2]), [s3] "v"(sc[3]), [s4] "v"(sc[4]), [s5] "v"(sc[5]), [s6] "v"(sc[6]), [s7] "v"(sc[7]), [s8] "v"(sc[8]), [s9] "v"(sc[9]), [s10] "v"(sc[10]), [s11] "v"(sc[11]), [s12] "v"(sc[12]), [s13] "v"(sc[13]), [s14] "v"(sc[14]), [s15] "v"(sc[15]), [m] "s"(0xFFFFFFF0u));
 }
@@ -705,8 +718,10 @@ __device__ __forceinline__ void search_tiles(const float *img, uint32_t ntiles, 
     if (t < ntiles) {                                                 // odd count: acc0 holds the last tile's init column
         const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
         half_step<R, MATCHED>(tile, img, tprev, tid, label, xf, acc0, acc1, a0, s_col, h, ku, km);
+        settle_mfma(acc0);
         last_screen<R, MATCHED>(acc0, tile, t, label, h, ku, km);
     } else {
+        settle_mfma(acc1);
         last_screen<R, MATCHED>(acc1, tprev, tid, label, h, ku, km);
     }
 }
@@ -753,6 +768,37 @@ __device__ __forceinline__ void split_fragment(const f32x4 (&xf)[R / 8], u32x4 (
     for (int q = 0; q < R / 16; ++q) split8(xf[2 * q], xf[2 * q + 1], bh[q], bl[q]);
 }
 
+// tile_mma with the products on the bf16 matrix cores: every split prototype fragment serves the S sample tiles of the wave
+template <int R, int S>
+__device__ __forceinline__ void tile_mma_bf(const float *tile, const u32x4 (&bh)[S][R / 16], const u32x4 (&bl)[S][R / 16], f32x16 (&acc)[S],
+                                            int row, int h)
+{
+    using Gm = Geom<R>;
+    const float *tail = tile + Gm::W_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
+            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
+        }
+    }
+    const float *rowp = tile + Gm::chunk_off(row, h);
+#pragma unroll
+    for (int q = 0; q < R / 16; ++q) {
+        u32x4 ah, al;
+        split8(*(const f32x4 *)(rowp + 16 * q), *(const f32x4 *)(rowp + 16 * q + 8), ah, al);
+        const bf16x8 vah = __builtin_bit_cast(bf16x8, ah), val = __builtin_bit_cast(bf16x8, al);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, __builtin_bit_cast(bf16x8, bh[s][q]), acc[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, __builtin_bit_cast(bf16x8, bl[s][q]), acc[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, __builtin_bit_cast(bf16x8, bh[s][q]), acc[s], 0, 0, 0);
+    }
+}
+
 // search_tiles with the products on the bf16 matrix cores; same keys, same contract.
 template <int R, bool MATCHED>
 __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntiles, uint32_t label, const u32x4 (&bh)[R / 16],
@@ -779,7 +825,7 @@ __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntile
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
         });
         // the wait states between the last MFMA and the first read of its result, tied to the accumulator so that they stay there
-        asm volatile("s_nop 15\n\ts_nop 1" : "+v"(acc));
+        settle_mfma(acc);
         last_screen<R, MATCHED>(acc, tile, t, label, h, ku, km);
     }
 }
