@@ -19,7 +19,7 @@ ROWS_BENCH  := tools/host_rows_bench
 
 MODELS_TEST_STATIC := tests/cpp/test_models_static
 
-all: $(LIB) $(LIBA) oracle $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream asan
+all: $(LIB) $(LIBA) oracle $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream tools/bf16x3_probe tools/issue_probe asan
 
 $(LIBA): $(OBJS)
 	rm -f $@ && ar rcs $@ $(OBJS)
@@ -30,6 +30,11 @@ $(MODELS_TEST_STATIC): tests/cpp/test_models.cpp include/vq_models.hpp include/v
 	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ $(LIBA) -L$(ROCM_LIB) -lamdhip64 -lpthread -Wl,-rpath,$(ROCM_LIB)
 
 tools/hbm_stream: tools/hbm_stream.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
+# measurement tools behind DESIGN.md: accuracy of the split-bf16 products, issue cost of the search's vector instructions
+tools/bf16x3_probe: tools/bf16x3_probe.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
+tools/issue_probe: tools/issue_probe.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
 
 # host-side code of the library (the image builders, duplicate detection, centring) under AddressSanitizer and UBSan,

@@ -104,8 +104,8 @@ static int run(int trials, int mode)
                 worst_f322 = std::fmax(worst_f322, std::fabs(B[m * 32 + n] - s) / sc2);
             }
     }
-    printf("D=%4d mode=%d trials=%d  bf16x3: %.3e of |x||w| (%.3e of (xx+ww)/2)   f32 mfma: %.3e (%.3e)   [3*2^-18 = %.3e]\n", D, mode, trials,
-           worst_bf, worst_bf2, worst_f32, worst_f322, 3.0 / 262144.0);
+    printf("D=%4d mode=%d trials=%d  bf16x3: %.3e of |x||w| (%.3e of (xx+ww)/2)   f32 mfma: %.3e (%.3e)   [bound 3*2^-16 = %.3e]\n", D, mode, trials,
+           worst_bf, worst_bf2, worst_f32, worst_f322, 3.0 / 65536.0);
     hipFree(dW); hipFree(dX); hipFree(dA); hipFree(dB);
     return 0;
 }
