@@ -480,7 +480,9 @@ def run_rank(args):
             torch.cuda.synchronize(dev)
             wall = time.perf_counter() - tw
             ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-            traffic, source = stored_traffic(name) if xrows == 10_000_000 and not f32_only else (None, None)
+            traffic, source = stored_traffic(name) if not f32_only else (None, None)
+            if traffic is not None and xrows != 10_000_000:     # every byte of these kernels' traffic is per batch of rows
+                traffic, source = traffic * xrows / 10_000_000, source + f" (profiled at 10000000 rows, scaled to {xrows})"
             entry = {"workload": f"{xc.model} predict, synthetic {xrows}x{xc.D} f32, {xc.K} prototypes"
                                  + (f", Omega {xc.M}x{xc.D} ({xc.omega})" if xc.omega != "none" else ""),
                      "value": xrows * n_launch / wall, "unit": "samples/s", "launches": n_launch, "ms_per_step": wall / n_launch * 1e3,
