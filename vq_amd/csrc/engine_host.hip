@@ -25,6 +25,12 @@ struct EngineModel {
     uint32_t *queue = nullptr;
     mutable uint32_t next_slot = 0;
     float *mu = nullptr;                                    // centre subtracted from every sample (R1 floats), null: none
+    // LDS-resident kernels that rank on the bf16 cores: bytes of LDS the kernel fills already, reduction length and image
+    // (1 / 2) of its search stage; what is left of LDS takes the bf16 pieces of the first nbf tiles (imgbf)
+    size_t lds_used = 0;
+    int search_R = 0, search_img = 1;
+    float *imgbf = nullptr;
+    uint32_t nbf = 0;
     uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
     const char *name = "mfma";
     LaunchFn launch = nullptr;
@@ -123,6 +129,51 @@ int variant_env()
 // The LDS-resident pipelined kernels rank the prototypes on the bf16 matrix cores (search_tiles_bf, mfma_device.h):
 // operands split into two bf16 pieces, three piece products.  Its margin: twice (3 * 2^-16 for the dropped parts + the
 // f32 accumulation of 3 R products + the key's 4 position bits), relative to ||x||^2 + max ||w||^2 like the f32 form's.
+// bf16 pieces of the first tiles of a search image, in the layout search_tiles_bf reads (mfma_device.h BF_TILE_BYTES):
+// rows at the f32 tile's pitch; per reduction step q and lane half h the hi pieces of the lane's 8 values (16 bytes), then
+// their lo pieces.  Round to nearest even like v_cvt_pk_bf16_f32; lo = bf16(v - hi) with the difference exact in f32.
+template <int R>
+std::vector<float> build_bf_tiles(const std::vector<float> &img, uint32_t nbf)
+{
+    using Gm = Geom<R>;
+    auto to_bf16 = [](float v) -> uint16_t {
+        uint32_t b;
+        std::memcpy(&b, &v, 4);
+        if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x40u);
+        b += 0x7FFFu + ((b >> 16) & 1u);
+        return (uint16_t)(b >> 16);
+    };
+    std::vector<float> out((size_t)nbf * Gm::W_FLOATS, 0.0f);
+    for (uint32_t t = 0; t < nbf; ++t)
+        for (int r = 0; r < TILE_ROWS; ++r) {
+            const float *row = &img[(size_t)t * Gm::TILE_FLOATS + (size_t)r * Gm::ROW_FLOATS];
+            uint16_t *dst = reinterpret_cast<uint16_t *>(&out[(size_t)t * Gm::W_FLOATS + (size_t)r * Gm::ROW_FLOATS]);
+            for (int q = 0; q < R / 16; ++q)
+                for (int h = 0; h < 2; ++h)
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = row[16 * q + 4 * h + (e < 4 ? e : e + 4)];     // chunks 4q + h and 4q + 2 + h
+                        const uint16_t hi = to_bf16(v);
+                        const uint32_t hb = (uint32_t)hi << 16;
+                        float hf;
+                        std::memcpy(&hf, &hb, 4);
+                        volatile float diff = v - hf;
+                        dst[32 * q + 16 * h + e] = hi;
+                        dst[32 * q + 16 * h + 8 + e] = to_bf16(diff);
+                    }
+        }
+    return out;
+}
+
+// as many tiles as LDS has room for behind what the kernel keeps there already
+template <int R>
+std::vector<float> bf_tiles_for(const EngineModel &m, const std::vector<float> &img, uint32_t &nbf)
+{
+    const size_t room = (size_t)RES_BYTES > m.lds_used ? (size_t)RES_BYTES - m.lds_used : 0;
+    nbf = (uint32_t)std::min<size_t>(res_tiles(m.K), room / ((size_t)Geom<R>::W_FLOATS * 4));
+    if (getenv("VQHIP_NO_BF_TILES")) nbf = 0;
+    return build_bf_tiles<R>(img, nbf);
+}
+
 void set_bf(EngineModel &m, int R)
 {
     if (getenv("VQHIP_NO_BF")) return;
@@ -169,6 +220,13 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     // k_engine and the pipelined resident kernels rank on the bf16 matrix cores (k_resident, padded rows, does not)
     const bool plain_diag = variant_env() == 31 || variant_env() == 32;
     if (R1 <= 128 && std::strcmp(m.name, "mfma_euclid_lds") != 0 && !plain_diag) set_bf(m, R1);
+    if (m.bf && std::strncmp(m.name, "mfma_euclid_lds_", 16) == 0) {      // pipe / staged / cut: the image is resident
+        size_t staging = 0;
+        if (std::strcmp(m.name, "mfma_euclid_lds_staged") == 0) (void)resident_staged_launcher(R1, &staging);
+        m.lds_used = (size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES + staging;
+        m.search_R = R1;
+        m.search_img = 1;
+    }
     return true;
 }
 
@@ -313,6 +371,9 @@ bool bind_lowrank(EngineModel &m, std::vector<float> &img1, std::vector<float> &
     m.samples_per_batch = 32;
     m.name = "mfma_omega_lowrank_lds";
     set_bf(m, 16);
+    m.lds_used = (size_t)res_tiles(m.K) * Geom<16>::TILE_BYTES + (size_t)16 * ROWF * sizeof(float);
+    m.search_R = 16;
+    m.search_img = 2;
     return true;
 }
 
@@ -345,6 +406,9 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     m.samples_per_batch = 32;
     m.name = "mfma_omega_lds";
     set_bf(m, R);
+    m.lds_used = (size_t)res_tiles(m.K) * Geom<R>::TILE_BYTES;
+    m.search_R = R;
+    m.search_img = 2;
     return true;
 }
 
@@ -539,8 +603,21 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         return nullptr;
     }
 
+    std::vector<float> imgbf;
+    if (m.bf && m.lds_used != 0) {
+        const std::vector<float> &simg = m.search_img == 1 ? img1 : img2;
+        switch (m.search_R) {
+        case 16: imgbf = bf_tiles_for<16>(m, simg, m.nbf); break;
+        case 32: imgbf = bf_tiles_for<32>(m, simg, m.nbf); break;
+        case 64: imgbf = bf_tiles_for<64>(m, simg, m.nbf); break;
+        case 128: imgbf = bf_tiles_for<128>(m, simg, m.nbf); break;
+        default: m.nbf = 0; break;
+        }
+    }
+
     EngineModel *out = new EngineModel(m);
     herr = to_device(&out->img1, img1);
+    if (herr == hipSuccess && !imgbf.empty()) herr = to_device(&out->imgbf, imgbf);
     if (herr == hipSuccess && !img2.empty()) herr = to_device(&out->img2, img2);
     if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
     if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
@@ -565,6 +642,7 @@ void engine_free(EngineModel *m)
     (void)hipFree(m->cls);
     (void)hipFree(m->queue);
     (void)hipFree(m->mu);
+    (void)hipFree(m->imgbf);
     delete m;
 }
 
@@ -599,6 +677,8 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.mu = m->mu;
     a.mscale = m->mscale;
     a.bf = m->bf ? 1u : 0u;
+    a.imgbf = m->imgbf;
+    a.nbf = m->imgbf ? m->nbf : 0u;
     a.cls = m->cls;
     hipError_t e = m->launch(a, dy != nullptr, s);
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch

@@ -49,9 +49,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         };
         to_lds(0u, (const char *)a.img2, p_bytes);
         to_lds(p_bytes, (const char *)a.img1, 16u * ROWF * 4u);
+        if constexpr (BF) to_lds(p_bytes + 16u * ROWF * 4u, (const char *)a.imgbf, a.nbf * (uint32_t)BF_TILE_BYTES<16>);
         __syncthreads();
     }
     const float *img = (const float *)smem;
+    const char *bfimg = smem + p_bytes + 16u * ROWF * 4u;             // bf16 pieces of the first a.nbf tiles
     const float *om = (const float *)(smem + p_bytes) + n16 * ROWF + kg * 4;   // this lane's Omega row and k group
 
     // blocks of BLOCK batches per wave: the first fixed, the others claimed a block ahead (BlockQueue)
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above stays f32
             u32x4 bh[1], bl[1];
             split_fragment<16>(yf, bh, bl);
-            search_tiles_bf<16, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km);
+            search_tiles_bf<16, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, a.nbf);
         } else {
             search_tiles<16, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
         }
@@ -229,9 +231,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
                                                  (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
         }
+        if constexpr (BF) {     // the bf16 pieces of the first a.nbf tiles behind the image
+            const uint32_t bbytes = a.nbf * (uint32_t)BF_TILE_BYTES<R>;
+            const char *bsrc = (const char *)a.imgbf;
+            for (uint32_t p = wave; p * 1024u < bbytes; p += NW) {
+                const uint32_t off = p * 1024u + lane * 16u;
+                if (off < bbytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + off),
+                                                     (__attribute__((address_space(3))) void *)(smem + bytes + p * 1024u), 16, 0, 0);
+            }
+        }
         __syncthreads();
     }
     const float *img = (const float *)smem;
+    const char *bfimg = smem + ntiles * Gs::TILE_BYTES;
     // Omega pieces: piece i = (tile i / NJ, step i % NJ), this lane's 16 bytes at i * 1024 + lane * 16
     const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, NSTEP * 1024, 0x00020000);
     const uint32_t om_off = (uint32_t)lane * 16u;
@@ -336,7 +349,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above stays f32
             u32x4 bh[R / 16], bl[R / 16];
             split_fragment<R>(yf, bh, bl);
-            search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km);
+            search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, a.nbf);
         } else {
             search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
         }

@@ -199,9 +199,21 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
                                                  (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
         }
+        if constexpr (BF) {     // the pieces of the first a.nbf tiles behind the image
+            const uint32_t bbytes = a.nbf * (uint32_t)BF_TILE_BYTES<R>;
+            const char *bsrc = (const char *)a.imgbf;
+            for (uint32_t p = wave; p * 1024u < bbytes; p += NW) {
+                const uint32_t off = p * 1024u + lane * 16u;
+                if (off < bbytes)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc + off),
+                                                     (__attribute__((address_space(3))) void *)(smem + bytes + p * 1024u), 16, 0, 0);
+            }
+        }
         __syncthreads();
     }
     const float *img = (const float *)smem;
+    const uint32_t nbf = BF ? a.nbf : 0u;
+    const char *bfimg = smem + ntiles * Gm::TILE_BYTES;
     unsigned long long t_begin = 0, r_begin = 0;
     if (DIAG) {
         tprev_ = t_begin = stamp();
@@ -235,7 +247,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
     };
     // STAGED: this wave's 32-row staging buffer behind the image
-    char *stage = smem + ntiles * Gm::TILE_BYTES + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * St::BYTES;
+    char *stage = smem + ntiles * Gm::TILE_BYTES + nbf * (uint32_t)BF_TILE_BYTES<R> + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * St::BYTES;
     // rows (and labels) of batch bb -> register set / label slot q, or -> the staging buffer
     auto fetch = [&](auto qq, uint64_t bb) {           // qq: label slot = position of bb in its block
         constexpr int q = decltype(qq)::value;
@@ -326,7 +338,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             if constexpr (BF) {
                 u32x4 bh[R / 16], bl[R / 16];
                 split_fragment<R>(xf, bh, bl);
-                search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km);
+                search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, nbf);
             } else {
                 search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
             }

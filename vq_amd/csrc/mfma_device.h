@@ -38,6 +38,8 @@ struct EngineArgs {
     const float *mu;          // centre subtracted from every sample before anything else (R1 floats, zero padded), or null
     float ss_limit;           // resident_pipe: ||x||^2 below which no screening score can overflow
     uint32_t bf;              // resident_pipe: screening products on the bf16 matrix cores (search_tiles_bf); mscale is then its margin
+    const float *imgbf;       // bf16 pieces of the first nbf tiles of the search image (as many as LDS has room for), or null
+    uint32_t nbf;
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
     const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
@@ -799,14 +801,42 @@ __device__ __forceinline__ void tile_mma_bf(const float *tile, const u32x4 (&bh)
     }
 }
 
-// search_tiles with the products on the bf16 matrix cores; same keys, same contract.
+// Bytes of one tile of bf16 pieces (host: build_bf_tiles): the rows of the f32 tile at the same pitch, each row holding,
+// per reduction step q and lane half h, the 8 hi pieces and then the 8 lo pieces of that lane's values (16 + 16 bytes).
+template <int R>
+constexpr int BF_TILE_BYTES = Geom<R>::W_FLOATS * 4;
+
+// search_tiles with the products on the bf16 matrix cores; same keys, same contract.  The first nbf tiles have their
+// pieces ready in LDS at bfimg (no split: the tile is bound by the matrix pipe), the others are split on the fly.
 template <int R, bool MATCHED>
 __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntiles, uint32_t label, const u32x4 (&bh)[R / 16],
-                                                const u32x4 (&bl)[R / 16], int s_col, int h, Keys2 &ku, KeysM &km)
+                                                const u32x4 (&bl)[R / 16], int s_col, int h, Keys2 &ku, KeysM &km,
+                                                const char *bfimg = nullptr, uint32_t nbf = 0)
 {
     using Gm = Geom<R>;
     constexpr int NQ = R / 16;
-    for (uint32_t t = 0; t < ntiles; ++t) {
+    uint32_t t = 0;
+    for (; t < nbf; ++t) {
+        const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ci = *(const f32x4 *)(tile + Gm::W_FLOATS + 8 * g + 4 * h);
+            acc[4 * g + 0] = ci[0]; acc[4 * g + 1] = ci[1]; acc[4 * g + 2] = ci[2]; acc[4 * g + 3] = ci[3];
+        }
+        const char *brow = bfimg + (size_t)t * BF_TILE_BYTES<R> + s_col * (Gm::ROW_FLOATS * 4) + h * 32;
+        static_for<0, NQ>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4 *)(brow + 64 * q));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4 *)(brow + 64 * q + 16));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+        });
+        settle_mfma(acc);
+        last_screen<R, MATCHED>(acc, tile, t, label, h, ku, km);
+    }
+    for (; t < ntiles; ++t) {
         const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
         f32x16 acc;
 #pragma unroll
