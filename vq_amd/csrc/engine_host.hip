@@ -31,6 +31,8 @@ struct EngineModel {
     int search_R = 0, search_img = 1;
     float *imgbf = nullptr;
     uint32_t nbf = 0;
+    bool bfimg = false;               // the search image holds pieces only (every tile); exact rows from `plain`
+    bool bfimg_ok = false;            // the kernel has that form (k_resident_pipe un-staged, k_omega_pipe)
     uint32_t ngroups1 = 0, ngroups2 = 0, ldp = 0;
     const char *name = "mfma";
     LaunchFn launch = nullptr;
@@ -164,6 +166,16 @@ std::vector<float> build_bf_tiles(const std::vector<float> &img, uint32_t nbf)
     return out;
 }
 
+// The search image with the f32 values of every tile replaced by their pieces (tails kept): the BFIMG kernels' image.
+template <int R>
+void pieces_image(std::vector<float> &img, uint32_t ntiles)
+{
+    using Gm = Geom<R>;
+    const std::vector<float> pieces = build_bf_tiles<R>(img, ntiles);
+    for (uint32_t t = 0; t < ntiles; ++t)
+        std::memcpy(&img[(size_t)t * Gm::TILE_FLOATS], &pieces[(size_t)t * Gm::W_FLOATS], (size_t)Gm::W_FLOATS * 4);
+}
+
 // as many tiles as LDS has room for behind what the kernel keeps there already
 template <int R>
 std::vector<float> bf_tiles_for(const EngineModel &m, const std::vector<float> &img, uint32_t &nbf)
@@ -223,6 +235,7 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     if (m.bf && std::strncmp(m.name, "mfma_euclid_lds_", 16) == 0) {      // pipe / staged / cut: the image is resident
         size_t staging = 0;
         if (std::strcmp(m.name, "mfma_euclid_lds_staged") == 0) (void)resident_staged_launcher(R1, &staging);
+        else m.bfimg_ok = variant_env() != 31 && variant_env() != 33;   // the diagnostic builds keep the f32 image
         m.lds_used = (size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES + staging;
         m.search_R = R1;
         m.search_img = 1;
@@ -409,6 +422,7 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     m.lds_used = (size_t)res_tiles(m.K) * Geom<R>::TILE_BYTES;
     m.search_R = R;
     m.search_img = 2;
+    m.bfimg_ok = true;
     return true;
 }
 
@@ -605,13 +619,25 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
 
     std::vector<float> imgbf;
     if (m.bf && m.lds_used != 0) {
-        const std::vector<float> &simg = m.search_img == 1 ? img1 : img2;
+        std::vector<float> &simg = m.search_img == 1 ? img1 : img2;
         switch (m.search_R) {
         case 16: imgbf = bf_tiles_for<16>(m, simg, m.nbf); break;
         case 32: imgbf = bf_tiles_for<32>(m, simg, m.nbf); break;
         case 64: imgbf = bf_tiles_for<64>(m, simg, m.nbf); break;
         case 128: imgbf = bf_tiles_for<128>(m, simg, m.nbf); break;
         default: m.nbf = 0; break;
+        }
+        // no room for every tile's pieces beside the f32 image: the image becomes the pieces, the exact rows come from L2
+        if (m.nbf < res_tiles(m.K) && m.bfimg_ok && !getenv("VQHIP_NO_BFIMG")) {
+            switch (m.search_R) {
+            case 16: pieces_image<16>(simg, res_tiles(m.K)); break;
+            case 32: pieces_image<32>(simg, res_tiles(m.K)); break;
+            case 64: pieces_image<64>(simg, res_tiles(m.K)); break;
+            default: pieces_image<128>(simg, res_tiles(m.K)); break;
+            }
+            m.bfimg = true;
+            m.nbf = 0;
+            imgbf.clear();
         }
     }
 
@@ -679,6 +705,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.bf = m->bf ? 1u : 0u;
     a.imgbf = m->imgbf;
     a.nbf = m->imgbf ? m->nbf : 0u;
+    a.bfimg = m->bfimg ? 1u : 0u;
     a.cls = m->cls;
     hipError_t e = m->launch(a, dy != nullptr, s);
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch

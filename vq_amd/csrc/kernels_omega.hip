@@ -208,7 +208,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
 // ahead of its MFMAs.  No LDS stage, no barrier after the image load: waves run independently and
 // claim batches from the queue.  The projection's accumulators are the search stage's B fragment
 // (engine.h), the search is k_resident_pipe's, distance squared and not rooted (helpers.rs:44).
-template <int R, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false>
+// BFIMG: the image of the projected prototypes holds their bf16 pieces (k_resident_pipe's BFIMG): search_pieces, exact
+// rows p_k from the plain matrix in L2.
+template <int R, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false, bool BFIMG = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs a)
 {
     using Gs = Geom<R>;
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
                                                  (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
         }
-        if constexpr (BF) {     // the bf16 pieces of the first a.nbf tiles behind the image
+        if constexpr (BF && !BFIMG) {     // the bf16 pieces of the first a.nbf tiles behind the image
             const uint32_t bbytes = a.nbf * (uint32_t)BF_TILE_BYTES<R>;
             const char *bsrc = (const char *)a.imgbf;
             for (uint32_t p = wave; p * 1024u < bbytes; p += NW) {
@@ -349,13 +351,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above stays f32
             u32x4 bh[R / 16], bl[R / 16];
             split_fragment<R>(yf, bh, bl);
-            search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, a.nbf);
+            if constexpr (BFIMG)
+                search_pieces<R, MATCHED>((const char *)img, (uint32_t)Gs::TILE_BYTES, img + Gs::W_FLOATS, ntiles, label, bh, bl, s_col, h, ku, km);
+            else
+                search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, a.nbf);
         } else {
             search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
         }
 
         Best1 wp, wn;
-        finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+        if constexpr (BFIMG) finish_keys_g<R, MATCHED, false>(yf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+        else finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
         {
             const int rec = (int)records(b, 4u);
             const uint32_t so = (uint32_t)s_col * 4u;
@@ -413,7 +419,17 @@ hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    if (a.bf) {
+    if (a.bf && a.bfimg) {
+        if (a.D < (uint32_t)R) {
+            if (matched)
+                hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_omega_pipe<R, false, true, 8, true, true>), dim3(grid), dim3(512), 0, st, a);
+        } else if (matched)
+            hipLaunchKernelGGL((k_omega_pipe<R, true, false, 8, true, true>), dim3(grid), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_omega_pipe<R, false, false, 8, true, true>), dim3(grid), dim3(512), 0, st, a);
+    } else if (a.bf) {
         if (a.D < (uint32_t)R) {
             if (matched)
                 hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true>), dim3(grid), dim3(512), 0, st, a);

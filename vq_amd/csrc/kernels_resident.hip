@@ -167,7 +167,12 @@ struct Staging {
 // split into bf16 pieces once per batch; the pieces die with the last tile, and without STAGED the next batch's rows
 // are requested into their registers right there (the f32 rows are still needed by the exact re-measurement):
 // two register sets that swap roles from batch to batch, the prefetch running over the epilogue and the partner wave.
-template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false, bool CUT = false, bool BF = false>
+//
+// BFIMG (with BF): the image in LDS holds the prototypes' bf16 PIECES instead of their f32 values (same tiles, same
+// tails; host: pieces_image) -- nothing is split in the tile loop (search_pieces), and the exact re-measurement reads
+// its one or two rows per sample from the model's plain matrix in L2 (finish_keys_g).  For models whose f32 image
+// leaves no room for the pieces beside it (config 2): the L2 reads cost the launch 6 %, the split they replace 20 %.
+template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false, bool CUT = false, bool BF = false, bool BFIMG = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
 {
     static_assert(!BF || R <= 128, "the bf16 pieces of a 256-value fragment do not fit beside the fragment");
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + off),
                                                  (__attribute__((address_space(3))) void *)(smem + p * 1024u), 16, 0, 0);
         }
-        if constexpr (BF) {     // the pieces of the first a.nbf tiles behind the image
+        if constexpr (BF && !BFIMG) {     // the pieces of the first a.nbf tiles behind the image
             const uint32_t bbytes = a.nbf * (uint32_t)BF_TILE_BYTES<R>;
             const char *bsrc = (const char *)a.imgbf;
             for (uint32_t p = wave; p * 1024u < bbytes; p += NW) {
@@ -212,7 +217,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         __syncthreads();
     }
     const float *img = (const float *)smem;
-    const uint32_t nbf = BF ? a.nbf : 0u;
+    const uint32_t nbf = BF && !BFIMG ? a.nbf : 0u;
     const char *bfimg = smem + ntiles * Gm::TILE_BYTES;
     unsigned long long t_begin = 0, r_begin = 0;
     if (DIAG) {
@@ -338,7 +343,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             if constexpr (BF) {
                 u32x4 bh[R / 16], bl[R / 16];
                 split_fragment<R>(xf, bh, bl);
-                search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, nbf);
+                if constexpr (BFIMG)
+                    search_pieces<R, MATCHED>((const char *)img, (uint32_t)Gm::TILE_BYTES, img + Gm::W_FLOATS, ntiles, label, bh, bl, s_col, h, ku, km);
+                else
+                    search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, nbf);
             } else {
                 search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
             }
@@ -349,7 +357,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             lap(2);                                    // 2: tile loop
 
             Best1 wp, wn;
-            finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+            if constexpr (BFIMG) finish_keys_g<R, MATCHED>(xf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+            else finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
             {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
                 const int rec = (int)records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;
@@ -429,6 +438,13 @@ hipError_t launch_resident_cut(const EngineArgs &a, bool matched, hipStream_t st
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if constexpr (R <= 128) {
+        if (a.bf && a.bfimg) {
+            if (matched)
+                hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, true, true, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, false, true, true, true>), dim3(grid), dim3(512), 0, st, a);
+            return hipGetLastError();
+        }
         if (a.bf) {
             if (matched)
                 hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, true, true>), dim3(grid), dim3(512), 0, st, a);
@@ -453,6 +469,13 @@ hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t s
     if (e != hipSuccess) return e;
     if constexpr (R <= 128 && !DIAG) {
         if (a.bf) {
+            if (a.bfimg) {
+                if (matched)
+                    hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, false, true, true>), dim3(grid), dim3(512), 0, st, a);
+                else
+                    hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, false, false, true, true>), dim3(grid), dim3(512), 0, st, a);
+                return hipGetLastError();
+            }
             if (matched)
                 hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, false, true>), dim3(grid), dim3(512), 0, st, a);
             else

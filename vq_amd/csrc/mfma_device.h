@@ -40,6 +40,7 @@ struct EngineArgs {
     uint32_t bf;              // resident_pipe: screening products on the bf16 matrix cores (search_tiles_bf); mscale is then its margin
     const float *imgbf;       // bf16 pieces of the first nbf tiles of the search image (as many as LDS has room for), or null
     uint32_t nbf;
+    uint32_t bfimg;           // the search image itself holds bf16 pieces (every tile); exact rows come from `plain`
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
     const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
@@ -806,8 +807,109 @@ __device__ __forceinline__ void tile_mma_bf(const float *tile, const u32x4 (&bh)
 template <int R>
 constexpr int BF_TILE_BYTES = Geom<R>::W_FLOATS * 4;
 
+// One tile of READY pieces into `acc` while the finished scores of the tile before (`prev`) are screened: half_step
+// for the bf16 cores.  Nothing is split here, so the tile is three MFMAs per step against two LDS reads; the screening
+// of the previous tile (one asm block) goes out behind the first step and runs while the partner wave owns the pipe.
+// On entry:  acc = accumulator-init column of the tile, (ph, pl) = this lane's pieces of its step 0,
+//            prev = finished scores of tile number tprev_id (class ids in tail_prev).
+// On exit:   acc = scores of the tile, prev = init column of the next tile (tail_next), (ph, pl) = its step-0 pieces.
+template <int R, bool MATCHED>
+__device__ __forceinline__ void pieces_step(const char *ptile, const char *pnext, const float *tail_next, const float *tail_prev,
+                                            uint32_t tprev_id, uint32_t label, const u32x4 (&bh)[R / 16], const u32x4 (&bl)[R / 16],
+                                            f32x16 &acc, f32x16 &prev, u32x4 &ph, u32x4 &pl, int row, int h, Keys2 &ku, KeysM &km)
+{
+    using Gm = Geom<R>;
+    constexpr int NQ = R / 16, ROWB = Gm::ROW_FLOATS * 4;
+    const char *rowp = ptile + row * ROWB + h * 32;
+    u32x4 ch = ph, cl = pl, nh = ph, nl = pl;
+    f32x16 cnext;
+    const Keys2 ou = ku;
+    const KeysM om = km;
+    static_for<0, NQ>([&](auto qq) {
+        constexpr int q = decltype(qq)::value;
+        if constexpr (q + 1 < NQ) {
+            nh = *(const u32x4 *)(rowp + 64 * (q + 1));
+            nl = *(const u32x4 *)(rowp + 64 * (q + 1) + 16);
+        } else {
+            ph = *(const u32x4 *)(pnext + row * ROWB + h * 32);
+            pl = *(const u32x4 *)(pnext + row * ROWB + h * 32 + 16);
+        }
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, ch), vl = __builtin_bit_cast(bf16x8, cl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+        if constexpr (q == 0) {
+            // prev's last MFMA sits three dependent MFMAs back; the wait states are kept all the same (bf16 MFMAs do
+            // not hold up the vector ALUs, and nothing pads hazards for inline asm)
+            if constexpr (!MATCHED) {
+                screen16<1>(prev, ku);
+                settle_tiles(ku, ou, tprev_id);
+            } else {
+                settle_mfma(prev);
+                const uint32_t *tcls = (const uint32_t *)tail_prev + 32 + 4 * h;
+                static_for<0, 16>([&](auto oo) {
+                    constexpr int o = decltype(oo)::value;
+                    const uint32_t key = pack_key(prev[o], o);
+                    const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;          // helpers.rs:113 / :122
+                    offer_m(km, match ? key : KEY_NONE, match ? KEY_NONE : key);
+                });
+                settle_tiles_m(km, om, tprev_id);
+            }
+        }
+        if constexpr (q == NQ / 2) {                   // NQ == 1: q == 0
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ci = *(const f32x4 *)(tail_next + 8 * g + 4 * h);
+                cnext[4 * g + 0] = ci[0]; cnext[4 * g + 1] = ci[1]; cnext[4 * g + 2] = ci[2]; cnext[4 * g + 3] = ci[3];
+            }
+        }
+        ch = nh;
+        cl = nl;
+    });
+    prev = cnext;
+}
+
+// The search over `ntiles` tiles whose pieces are ready in LDS: tile t's pieces at pbase + t * pstride (layout:
+// BF_TILE_BYTES), its tail (init column, class ids) at tails + t * TILE_FLOATS.  Two accumulators, as search_tiles.
+template <int R, bool MATCHED>
+__device__ __forceinline__ void search_pieces(const char *pbase, uint32_t pstride, const float *tails, uint32_t ntiles, uint32_t label,
+                                              const u32x4 (&bh)[R / 16], const u32x4 (&bl)[R / 16], int s_col, int h, Keys2 &ku, KeysM &km)
+{
+    using Gm = Geom<R>;
+    constexpr int ROWB = Gm::ROW_FLOATS * 4;
+    f32x16 acc0, acc1;
+    u32x4 ph = *(const u32x4 *)(pbase + s_col * ROWB + h * 32), pl = *(const u32x4 *)(pbase + s_col * ROWB + h * 32 + 16);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(tails + 8 * g + 4 * h);
+        acc0[4 * g + 0] = ci[0]; acc0[4 * g + 1] = ci[1]; acc0[4 * g + 2] = ci[2]; acc0[4 * g + 3] = ci[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = PAD_SCORE;                 // "tile -1": its keys never win
+    const float *tail_prev = tails;
+    uint32_t tid = 0, t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+        const char *p0 = pbase + (size_t)t * pstride, *p1 = p0 + pstride, *pn = t + 2 < ntiles ? p1 + pstride : pbase;
+        const float *tl0 = tails + (size_t)t * Gm::TILE_FLOATS, *tl1 = tl0 + Gm::TILE_FLOATS;
+        const float *tln = t + 2 < ntiles ? tl1 + Gm::TILE_FLOATS : tails;
+        pieces_step<R, MATCHED>(p0, p1, tl1, tail_prev, tid, label, bh, bl, acc0, acc1, ph, pl, s_col, h, ku, km);
+        pieces_step<R, MATCHED>(p1, pn, tln, tl0, t, label, bh, bl, acc1, acc0, ph, pl, s_col, h, ku, km);
+        tail_prev = tl1;
+        tid = t + 1;
+    }
+    if (t < ntiles) {                                                 // odd count: acc0 holds the last tile's init column
+        const float *tl = tails + (size_t)t * Gm::TILE_FLOATS;
+        pieces_step<R, MATCHED>(pbase + (size_t)t * pstride, pbase, tails, tail_prev, tid, label, bh, bl, acc0, acc1, ph, pl, s_col, h, ku, km);
+        settle_mfma(acc0);
+        last_screen<R, MATCHED>(acc0, tl - Gm::W_FLOATS, t, label, h, ku, km);
+    } else if (ntiles != 0) {
+        settle_mfma(acc1);
+        last_screen<R, MATCHED>(acc1, tail_prev - Gm::W_FLOATS, tid, label, h, ku, km);
+    }
+}
+
 // search_tiles with the products on the bf16 matrix cores; same keys, same contract.  The first nbf tiles have their
-// pieces ready in LDS at bfimg (no split: the tile is bound by the matrix pipe), the others are split on the fly.
+// pieces ready in LDS at bfimg (search_pieces), the others are split on the fly.
 template <int R, bool MATCHED>
 __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntiles, uint32_t label, const u32x4 (&bh)[R / 16],
                                                 const u32x4 (&bl)[R / 16], int s_col, int h, Keys2 &ku, KeysM &km,
@@ -815,27 +917,8 @@ __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntile
 {
     using Gm = Geom<R>;
     constexpr int NQ = R / 16;
-    uint32_t t = 0;
-    for (; t < nbf; ++t) {
-        const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
-        f32x16 acc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 ci = *(const f32x4 *)(tile + Gm::W_FLOATS + 8 * g + 4 * h);
-            acc[4 * g + 0] = ci[0]; acc[4 * g + 1] = ci[1]; acc[4 * g + 2] = ci[2]; acc[4 * g + 3] = ci[3];
-        }
-        const char *brow = bfimg + (size_t)t * BF_TILE_BYTES<R> + s_col * (Gm::ROW_FLOATS * 4) + h * 32;
-        static_for<0, NQ>([&](auto qq) {
-            constexpr int q = decltype(qq)::value;
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const u32x4 *)(brow + 64 * q));
-            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const u32x4 *)(brow + 64 * q + 16));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
-        });
-        settle_mfma(acc);
-        last_screen<R, MATCHED>(acc, tile, t, label, h, ku, km);
-    }
+    if (nbf != 0) search_pieces<R, MATCHED>(bfimg, (uint32_t)BF_TILE_BYTES<R>, img + Gm::W_FLOATS, nbf, label, bh, bl, s_col, h, ku, km);
+    uint32_t t = nbf;
     for (; t < ntiles; ++t) {
         const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
         f32x16 acc;
@@ -911,6 +994,76 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         group(km.n, km.tn, km.n2, km.tn2, km.n3, wn);
     }
     if (unsafe) scan_exact_lds<R, MATCHED, ROOT>(xf, img, K, label, h, wp, wn);      // helpers.rs:55-77 in f32, rows from LDS
+}
+
+// ------------------------------------------------------------------------------ the same with the exact rows in global memory
+// exact_sq_lds / scan_exact_lds / finish_keys for kernels whose LDS holds no f32 image: the rows come from the model's
+// plain matrix (K x ldp, zero padded; L2-resident: at most a few MiB), same sums in the same order, so a winner's
+// distance does not depend on where its row was read.
+template <int R>
+__device__ __forceinline__ float exact_sq_g(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t k, int h)
+{
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const float *w = plain + (size_t)k * ldp + 4 * h;
+    f32x2 p = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 v = *(const f32x4 *)(w + 8 * j);
+        const f32x2 d0 = f32x2{xf[j][0], xf[j][1]} - f32x2{v[0], v[1]};
+        const f32x2 d1 = f32x2{xf[j][2], xf[j][3]} - f32x2{v[2], v[3]};
+        p = __builtin_elementwise_fma(d0, d0, p);
+        p = __builtin_elementwise_fma(d1, d1, p);
+    }
+    const float t = p[0] + p[1];
+    return t + xor32(t);
+}
+
+template <int R, bool MATCHED, bool ROOT = true>
+__device__ __forceinline__ void finish_keys_g(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, const uint32_t *cls, uint32_t K,
+                                              uint32_t label, int h, bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp,
+                                              Best1 &wn)
+{
+    auto dist = [&](uint32_t k) {
+        const float d = exact_sq_g<R>(xf, plain, ldp, k, h);
+        return ROOT ? sqrtf(d) : d;
+    };
+    const bool skip = unsafe;
+    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w) {
+        uint32_t f, fi, sd, si;
+        merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
+        const float third = pair_third(b1, b2, b3);
+        const bool have = key_valid(f) && !skip;
+        const float fk = __builtin_bit_cast(float, f);
+        float d1 = INFINITY;
+        if (have) {
+            d1 = dist(fi);
+            w.d = d1; w.i = fi;
+        }
+        const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - fk > margin);
+        if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+            if (have && key_valid(sd)) {
+                const float d2 = dist(si);
+                if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
+            }
+        }
+        if (have) unsafe |= !(third - fk > margin) || !(w.d < INFINITY);
+        return have;
+    };
+    if (!MATCHED) {
+        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp)) unsafe = true;
+    } else {
+        group(km.p, km.tp, km.p2, km.tp2, km.p3, wp);
+        group(km.n, km.tn, km.n2, km.tn2, km.n3, wn);
+    }
+    if (unsafe) {                                       // helpers.rs:55-77 / 91-132 in f32, in index order
+        wp = Best1();
+        wn = Best1();
+        for (uint32_t k = 0; k < K; ++k) {
+            const float d = dist(k);
+            if (!MATCHED || cls[k] == label) wp.offer(d, k);
+            else wn.offer(d, k);
+        }
+    }
 }
 
 }  // namespace
