@@ -207,7 +207,7 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
             m.launch = resident_launcher(R1, &m.samples_per_batch);
             m.name = "mfma_euclid_lds";
         }
-        const bool diag = variant_env() == 31 || variant_env() == 33;
+        const bool diag = variant_env() == 31 || variant_env() == 33 || variant_env() == 35;
         if (m.D == (uint32_t)R1 && pipe_ok && resident_pipe_launcher(R1, diag)) {   // unpadded rows: the pipelined kernel
             m.samples_per_batch = 32;
             m.launch = resident_pipe_launcher(R1, diag);
@@ -695,7 +695,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.wmax2 = m->wmax2;
     a.dbg = nullptr;
     static unsigned long long *dbg_buf = nullptr;                     // diagnostic build only (VQHIP_VARIANT=14)
-    if ((variant_env() >= 31 && variant_env() <= 33) && !queue) {
+    if ((variant_env() >= 31 && variant_env() <= 35) && !queue) {
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
@@ -718,7 +718,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
             for (int i = 0; i < 8; ++i) sum[i] += (double)h[w * 8 + i];
         double tot = 0;
         for (int i = 0; i < 7; ++i) tot += sum[i];
-        if (variant_env() >= 31 && variant_env() <= 33) {
+        if (variant_env() >= 31 && variant_env() <= 35) {
             double s4[6] = {0};
             for (size_t w = 0; w < (size_t)256 * (getenv("VQHIP_NW4") ? 4 : 8); ++w)
                 for (int i = 0; i < 6; ++i) s4[i] += (double)h[w * 8 + i];

@@ -350,14 +350,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             } else {
                 search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
             }
-            if constexpr (SWAP) {                      // the pieces are dead: the next batch's rows take their registers
+            auto fetch_next = [&]() { fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0); };
+            constexpr bool AHEAD = BFIMG && SWAP && !MATCHED;   // the fetch goes out inside finish_keys_ahead instead
+            if constexpr (SWAP && !AHEAD) {            // the pieces are dead: the next batch's rows take their registers
                 asm volatile("" ::: "memory");
-                fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
+                fetch_next();
             }
             lap(2);                                    // 2: tile loop
 
             Best1 wp, wn;
-            if constexpr (BFIMG) finish_keys_g<R, MATCHED>(xf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+            if constexpr (AHEAD)       // the next batch's rows go out behind the request for the candidate's row
+                finish_keys_ahead<R>(xf, a.plain, a.ldp, a.K, h, unsafe, margin, ku, wp, [&]() { fetch_next(); });
+            else if constexpr (BFIMG)
+                finish_keys_g<R, MATCHED>(xf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
             else finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
             {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
                 const int rec = (int)records(b, 4u);
@@ -484,6 +489,10 @@ hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t s
         }
     }
     if constexpr (DIAG && R == 128) {
+        if (a.bf && a.bfimg) {                                        // VQHIP_VARIANT=35: the same with the pieces image
+            hipLaunchKernelGGL((k_resident_pipe<R, false, true, 8, false, false, true, true>), dim3(grid), dim3(512), 0, st, a);
+            return hipGetLastError();
+        }
         if (a.bf) {                                                   // VQHIP_VARIANT=33: phase stamps of the bf16 search
             hipLaunchKernelGGL((k_resident_pipe<R, false, true, 8, false, false, true>), dim3(grid), dim3(512), 0, st, a);
             return hipGetLastError();

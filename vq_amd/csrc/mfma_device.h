@@ -1066,6 +1066,76 @@ __device__ __forceinline__ void finish_keys_g(const f32x4 (&xf)[R / 8], const fl
     }
 }
 
+// A prototype's row for this lane's chunks, requested now and used later (rows_sq).  Through a buffer descriptor over
+// the whole plain matrix: an index that is not a row of it reads zeros instead of faulting.
+template <int R>
+__device__ __forceinline__ void load_row_g(f32x4 (&w)[R / 8], __amdgpu_buffer_rsrc_t rplain, uint32_t ldp, uint32_t k, int h)
+{
+    const uint32_t off = (k * ldp + 4u * (uint32_t)h) * 4u;
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rplain, off, j * 32, 0));
+}
+template <int R>
+__device__ __forceinline__ float rows_sq(const f32x4 (&xf)[R / 8], const f32x4 (&w)[R / 8])
+{
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    f32x2 p = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x2 d0 = f32x2{xf[j][0], xf[j][1]} - f32x2{w[j][0], w[j][1]};
+        const f32x2 d1 = f32x2{xf[j][2], xf[j][3]} - f32x2{w[j][2], w[j][3]};
+        p = __builtin_elementwise_fma(d0, d0, p);
+        p = __builtin_elementwise_fma(d1, d1, p);
+    }
+    const float t = p[0] + p[1];
+    return t + xor32(t);
+}
+
+// finish_keys_g for the unlabelled search, with the best candidate's row REQUESTED before `between` runs and used after
+// it: the caller issues the next batch's sample loads in `between` -- vmcnt completes in order, so loads issued ahead
+// of the candidate's row would have to land first, and those come from HBM (measured on config 2: 15.4k cycles of
+// epilogue per batch with the samples requested first, 5.8k this way).  Same sums as exact_sq_g.
+template <int R, bool ROOT = true, class Between>
+__device__ __forceinline__ void finish_keys_ahead(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t K, int h, bool unsafe,
+                                                  float margin, const Keys2 &ku, Best1 &wp, Between &&between)
+{
+    const __amdgpu_buffer_rsrc_t rplain = __builtin_amdgcn_make_buffer_rsrc((void *)plain, 0, (int)(K * ldp * 4u), 0x00020000);
+    auto dist = [&](uint32_t k) {
+        f32x4 w[R / 8];
+        load_row_g<R>(w, rplain, ldp, k, h);
+        const float d = rows_sq<R>(xf, w);
+        return ROOT ? sqrtf(d) : d;
+    };
+    uint32_t f, fi, sd, si;
+    merge_pair(ku.b1, ku.t1, ku.b2, ku.t2, h, f, fi, sd, si);
+    const float third = pair_third(ku.b1, ku.b2, ku.b3);
+    const bool have = key_valid(f) && !unsafe;
+    const float fk = __builtin_bit_cast(float, f);
+    f32x4 row[R / 8];
+    load_row_g<R>(row, rplain, ldp, have ? fi : 0u, h);
+    asm volatile("" ::: "memory");
+    between();
+    asm volatile("" ::: "memory");
+    float d1 = INFINITY;
+    if (have) {
+        d1 = rows_sq<R>(xf, row);
+        if (ROOT) d1 = sqrtf(d1);
+        wp.d = d1; wp.i = fi;
+    }
+    const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - fk > margin);
+    if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+        if (have && key_valid(sd)) {
+            const float d2 = dist(si);
+            if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+        }
+    }
+    // crowded (a third key within the margin), a non-finite winner, or no usable key at all: the exact scan answers
+    if (!have || !(third - fk > margin) || !(wp.d < INFINITY)) {
+        wp = Best1();                                   // helpers.rs:55-77 in f32, in index order
+        for (uint32_t k = 0; k < K; ++k) wp.offer(dist(k), k);
+    }
+}
+
 }  // namespace
 
 }  // namespace vq
