@@ -68,6 +68,9 @@ SHAPES = [
     ("lvq_k20_staged", 128, 20, 0, "mfma_euclid_lds_staged"),
     ("glvq_d100_cut", 100, 37, 0, "mfma_euclid_lds_pipe_cut"),
     ("glvq_d16", 16, 300, 0, "mfma_euclid_lds_pipe"),
+    ("vq_d32_k800_pieces_image", 32, 800, 0, "mfma_euclid_lds_pipe"),       # the LDS image holds bf16 pieces (BFIMG), R = 32
+    ("vq_d64_k400_pieces_image", 64, 400, 0, "mfma_euclid_lds_pipe"),       # the same at R = 64
+    ("glvq_d120_k200_cut_pieces_image", 120, 200, 0, "mfma_euclid_lds_pipe_cut"),
     ("gmlvq_c3", 128, 256, 128, "mfma_omega_lds"),
     ("liramlvq_c4", 256, 1024, 16, "mfma_omega_lowrank_lds"),
     ("vq_k1024_streamed", 128, 1024, 0, "mfma_euclid"),
