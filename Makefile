@@ -19,7 +19,7 @@ ROWS_BENCH  := tools/host_rows_bench
 
 MODELS_TEST_STATIC := tests/cpp/test_models_static
 
-all: $(LIB) $(LIBA) oracle $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream tools/bf16x3_probe tools/issue_probe asan
+all: $(LIB) $(LIBA) oracle $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream tools/bf16x3_probe tools/bf16x6_probe tools/issue_probe asan
 
 $(LIBA): $(OBJS)
 	rm -f $@ && ar rcs $@ $(OBJS)
@@ -33,6 +33,8 @@ tools/hbm_stream: tools/hbm_stream.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
 # measurement tools behind DESIGN.md: accuracy of the split-bf16 products, issue cost of the search's vector instructions
 tools/bf16x3_probe: tools/bf16x3_probe.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
+tools/bf16x6_probe: tools/bf16x6_probe.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
 tools/issue_probe: tools/issue_probe.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@

@@ -130,17 +130,24 @@ def bytes_per_sample(cfg):
     return cfg.D * 4 + 8                                      # sample row in, u32 index + f32 distance out
 
 
-def matrix_work(cfg, ranking):
+def matrix_work(cfg, ranking, projection="f32"):
     """Per sample: (flops the f32 matrix cores execute, flops the bf16 matrix cores execute).  With ranking "bf16x3" the
-    search products (2 K L of the algorithmic flops) run as three bf16 piece products each; projections stay f32."""
+    search products (2 K L of the algorithmic flops) run as three bf16 piece products each; with projection "bf16x6"
+    the projection's products (the rest of an Omega model's flops) run as six."""
     fl = flops_per_sample(cfg)
-    if ranking != "bf16x3":
-        return fl, 0
-    search = 2 * cfg.K * (cfg.D if cfg.omega == "none" else cfg.M)
-    return fl - search, 3 * search
+    search = 2 * cfg.K * (cfg.D if cfg.omega == "none" else cfg.M) if cfg.omega != "local" else 0
+    proj = fl - search
+    f32_fl, bf_fl = fl, 0
+    if ranking == "bf16x3":
+        f32_fl -= search
+        bf_fl += 3 * search
+    if projection == "bf16x6":
+        f32_fl -= proj
+        bf_fl += 6 * proj
+    return f32_fl, bf_fl
 
 
-def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=None, ranking="f32"):
+def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=None, ranking="f32", projection="f32"):
     """achieved = ALGORITHMIC flops (or bytes) per launch / launch time.  MFMA peak = the same algorithmic flops over the
     least time the matrix cores need for the instructions this kernel issues for them: f32 products at 157.3 TFLOP/s and,
     where the candidates are ranked on the bf16 cores, three bf16 piece products per algorithmic product at 2 516.6
@@ -149,10 +156,10 @@ def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=No
     secs = launch_ms * 1e-3
     tflops = rows * fl / secs / 1e12
     gbs = rows * by / secs / 1e9
-    f32_fl, bf_fl = matrix_work(cfg, ranking)
+    f32_fl, bf_fl = matrix_work(cfg, ranking, projection)
     t_min = f32_fl / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf_fl / (PEAK_BF16_MFMA_TFLOPS * 1e12)       # per sample
     mfma_peak = fl / t_min / 1e12
-    blk = {"kernel": KERNEL_FN.get(kernel, "k_engine"), "ranking": ranking, "launch_ms": launch_ms, "samples_per_launch": rows,
+    blk = {"kernel": KERNEL_FN.get(kernel, "k_engine"), "ranking": ranking, "projection": projection, "launch_ms": launch_ms, "samples_per_launch": rows,
            "flops_per_sample": fl, "bytes_per_sample": by, "traffic": traffic, "traffic_source": traffic_source,
            "tflops": tflops, "mfma_frac_of_157.3": tflops / PEAK_F32_MFMA_TFLOPS,
            "f32_mfma_flops_per_sample": f32_fl, "bf16_mfma_flops_per_sample": bf_fl,
@@ -162,10 +169,11 @@ def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=No
         blk.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
     else:
         blk.update({"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tflops / mfma_peak})
-        if ranking == "bf16x3":
-            blk["peak_note"] = ("algorithmic flops over the matrix cores' least time for this instruction mix: f32 MFMA at 157.3 TFLOP/s "
-                                "for projections, 3 bf16 piece products per search product at 2516.6; results are the f32 path's "
-                                "(exact f32 re-measurement + in-kernel guard)")
+        if ranking == "bf16x3" or projection == "bf16x6":
+            blk["peak_note"] = ("algorithmic flops over the matrix cores' least time for this instruction mix: f32 MFMA at 157.3 TFLOP/s, "
+                                "3 bf16 piece products per search product and 6 per projection product (where vqhip_last_projection says "
+                                "bf16x6) at 2516.6; the ranking changes no result (exact f32 re-measurement + in-kernel guard), the "
+                                "bf16x6 projection is as exact as the f32 chain (tools/bf16x6_probe.hip)")
     return blk
 
 
@@ -440,8 +448,9 @@ def run_rank(args):
                 traffic, source = stored_traffic(args.workload)
                 if traffic is not None and why:
                     source += f" (live collection: {why})"
-            line["roofline"] = roofline_block(cfg, kernel, m_rows, launch_ms, traffic, source, ctx.last_ranking)
+            line["roofline"] = roofline_block(cfg, kernel, m_rows, launch_ms, traffic, source, ctx.last_ranking, ctx.last_projection)
             line["config"]["ranking"] = ctx.last_ranking
+            line["config"]["projection"] = ctx.last_projection
             if world == 1 and args.cpu_rows != 0:
                 line["cpu_baseline"] = cpu_baselines(cfg, model, sh.first_row(0), args.cpu_rows if args.cpu_rows > 0 else 0,
                                                      idx_loc[0].cpu().numpy(), budget_s=6.0)
@@ -486,8 +495,8 @@ def run_rank(args):
             entry = {"workload": f"{xc.model} predict, synthetic {xrows}x{xc.D} f32, {xc.K} prototypes"
                                  + (f", Omega {xc.M}x{xc.D} ({xc.omega})" if xc.omega != "none" else ""),
                      "value": xrows * n_launch / wall, "unit": "samples/s", "launches": n_launch, "ms_per_step": wall / n_launch * 1e3,
-                     "kernel": ctx.last_kernel, "ranking": ctx.last_ranking,
-                     "roofline": roofline_block(xc, ctx.last_kernel, xrows, ms, traffic, source, ctx.last_ranking)}
+                     "kernel": ctx.last_kernel, "ranking": ctx.last_ranking, "projection": ctx.last_projection,
+                     "roofline": roofline_block(xc, ctx.last_kernel, xrows, ms, traffic, source, ctx.last_ranking, ctx.last_projection)}
             if args.cpu_rows != 0 and not f32_only:
                 entry["cpu_baseline"] = cpu_baselines(xc, xm, 0, 0, xi.cpu().numpy(), budget_s=2.5)
             line["extra"][name] = entry

@@ -206,6 +206,14 @@ const char *vqhip_last_kernel(const vqhip_ctx *ctx);
  * guard sends every sample whose ranking could be wrong to an exact scan, so both settings return the same results. */
 const char *vqhip_last_ranking(const vqhip_ctx *ctx);
 
+/* Where the last assign call computed the projection y = Omega x of the Omega models (src/helpers.rs:41-43): "f32"
+ * (v_mfma_f32_32x32x2_f32 / 16x16x4), "bf16x6" (Omega and x each split into three bf16 pieces that add up to the f32
+ * value exactly, the six piece products down to 2^-16 of the leading one on v_mfma_f32_32x32x16_bf16, accumulated in
+ * f32: measured at or below the f32 chain's error, tools/bf16x6_probe.hip; VQHIP_NO_BF_PROJ turns it off) or "none"
+ * (Euclidean models).  Unlike the ranking this is part of the result: the distances are measured on this y, to the
+ * same 1e-5 bar against the f64 oracle either way. */
+const char *vqhip_last_projection(const vqhip_ctx *ctx);
+
 /* Counter-based synthetic data: value(seed, stream, i) in [-1, 1) as f32.
  * The host and device fills produce identical bits, so the CPU checker can regenerate any index
  * range of a device-resident matrix.  out[i] = base_scale * (base ? base[(first+i) % base_len] : 0)

@@ -21,9 +21,8 @@ from vq_amd import KERNEL_AUTO, Context
 pytestmark = pytest.mark.gpu
 
 
-def _run(X, W, Om, cls, y, no_bf):
-    if no_bf:
-        os.environ["VQHIP_NO_BF"] = "1"
+def _run(X, W, Om, cls, y, env):
+    os.environ.update(env)
     try:
         ctx = Context(0)
         ctx.set_kernel_policy(KERNEL_AUTO)
@@ -31,14 +30,15 @@ def _run(X, W, Om, cls, y, no_bf):
         if Om is not None:
             ctx.set_omega(Om)
         idx, dist = ctx.assign(X)
-        out = {"kernel": ctx.last_kernel, "ranking": ctx.last_ranking, "idx": idx, "dist": dist}
+        out = {"kernel": ctx.last_kernel, "ranking": ctx.last_ranking, "projection": ctx.last_projection, "idx": idx, "dist": dist}
         ctx.set_labels(cls)
         out["matched"] = ctx.assign_matched(X, y)
-        assert ctx.last_ranking == out["ranking"]
+        assert ctx.last_ranking == out["ranking"] and ctx.last_projection == out["projection"]
         ctx.close()
         return out
     finally:
-        os.environ.pop("VQHIP_NO_BF", None)
+        for k in env:
+            os.environ.pop(k, None)
 
 
 def _data(kind, rng, N, K, D):
@@ -88,14 +88,31 @@ def test_bf16_ranking_returns_the_f32_rankings_results(shape, kind):
     Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32) if M else None
     cls = (np.arange(K) % 3).astype(np.uint32)
     y = rng.integers(0, 3, size=N).astype(np.uint32)
-    bf = _run(X, W, Om, cls, y, no_bf=False)
-    f32 = _run(X, W, Om, cls, y, no_bf=True)
+    # the projection is part of the result (vqhip_last_projection), the ranking is not: the rankings are compared with
+    # the projection held on the f32 matrix cores; the bf16x6 projection is checked against the oracle below
+    bf = _run(X, W, Om, cls, y, {"VQHIP_NO_BF_PROJ": "1"})
+    f32 = _run(X, W, Om, cls, y, {"VQHIP_NO_BF": "1"})
     assert bf["kernel"] == kernel and f32["kernel"] == kernel, (bf["kernel"], f32["kernel"])
     assert bf["ranking"] == "bf16x3" and f32["ranking"] == "f32", (bf["ranking"], f32["ranking"])
+    assert bf["projection"] == f32["projection"] == ("f32" if M else "none")
     assert np.array_equal(bf["idx"], f32["idx"]), f"{int((bf['idx'] != f32['idx']).sum())} winners differ"
     assert np.array_equal(bf["dist"].view(np.uint32), f32["dist"].view(np.uint32)), "distances differ"
     for a, b, what in zip(bf["matched"], f32["matched"], ("j+", "d+", "j-", "d-")):
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32)), f"matched {what} differs"
+    if kernel == "mfma_omega_lds":      # the default: ranking AND projection on the bf16 matrix cores
+        bf = _run(X, W, Om, cls, y, {})
+        assert bf["kernel"] == kernel and bf["ranking"] == "bf16x3" and bf["projection"] == "bf16x6", bf
+        # against the f32 projection: the winner's distance agrees to the oracle's bar whichever index carries it, and
+        # the index differs only where two prototypes are that close (near-ties)
+        def same(j, d, fj, fd, what):
+            d, fd = np.asarray(d, dtype=np.float64), np.asarray(fd, dtype=np.float64)
+            fin = np.isfinite(fd)
+            assert np.array_equal(np.isfinite(d), fin), what
+            assert np.all(np.abs(d[fin] - fd[fin]) <= 2e-5 * np.abs(fd[fin]) + 2e-6), (what, float(np.abs(d[fin] - fd[fin]).max()))
+            assert int((np.asarray(j) != np.asarray(fj)).sum()) <= max(2, N // 500), what
+        same(bf["idx"], bf["dist"], f32["idx"], f32["dist"], "plain")
+        same(bf["matched"][0], bf["matched"][1], f32["matched"][0], f32["matched"][1], "matched +")
+        same(bf["matched"][2], bf["matched"][3], f32["matched"][2], f32["matched"][3], "matched -")
     # and the shared answer is the oracle's (a subset keeps the f64 oracle quick on the Omega shapes)
     sel = slice(0, 400 if M else N)
     rep = parity.compare(bf["idx"][sel], bf["dist"][sel], *oracle.assign(X[sel], W, omega=Om, threads=8), atol=2e-6 if M else 0.0)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "vqhip_assign_matched_device": (C.c_int, [_v, _v, _v, C.c_uint64, _v, _v, _v, _v, _v]),
     "vqhip_last_kernel": (C.c_char_p, [_v]),
     "vqhip_last_ranking": (C.c_char_p, [_v]),
+    "vqhip_last_projection": (C.c_char_p, [_v]),
     "vqhip_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
     "vqhip_multi_destroy": (C.c_int, [_v]),
     "vqhip_multi_last_error": (C.c_char_p, [_v]),

@@ -103,6 +103,11 @@ class Context:
         """Where the last assign call ranked its candidates: "f32", "bf16x3" or "none" (vqhip_last_ranking)."""
         return self._L.vqhip_last_ranking(self._h).decode()
 
+    @property
+    def last_projection(self) -> str:
+        """Where the last assign call computed y = Omega x: "f32", "bf16x6" or "none" (vqhip_last_projection)."""
+        return self._L.vqhip_last_projection(self._h).decode()
+
     # -- hot path
     def assign(self, X, want_dist: bool = True):
         """find_closest_prototype for every row of X -> (idx, dist).

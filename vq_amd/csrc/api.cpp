@@ -63,6 +63,7 @@ struct vqhip_ctx {
     std::string err;
     const char *last_kernel = "none";
     const char *last_ranking = "none";
+    const char *last_projection = "none";
     int policy = VQHIP_KERNEL_AUTO;
 
     uint32_t K = 0, D = 0, M = 0;
@@ -294,6 +295,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
     if (c->engine && c->policy != VQHIP_KERNEL_SCALAR) {      // (an engine built before the policy was set to scalar stays unused)
         c->last_kernel = engine_name(c->engine);
         c->last_ranking = engine_ranking(c->engine);
+        c->last_projection = engine_projection(c->engine);
         HIPCHK(c, engine_assign(c->engine, dX, N, dy, out, s));
         return VQHIP_OK;
     }
@@ -319,11 +321,13 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
         }
         c->last_kernel = "mfma_omega_two_pass";
         c->last_ranking = engine_ranking(c->engine2);
+        c->last_projection = "f32";
         return scratch_release(c, s);
     }
 
     c->last_kernel = "scalar";
     c->last_ranking = "none";
+    c->last_projection = c->omega_kind == OMEGA_NONE ? "none" : "f32";
     if (c->omega_kind == OMEGA_NONE) {
         HIPCHK(c, launch_assign_scalar(dX, N, c->D, c->dW, c->K, c->dcls, dy, /*rooted=*/true, out, s));
     } else if (c->omega_kind == OMEGA_GLOBAL) {
@@ -798,6 +802,7 @@ const char *vqhip_last_error(const vqhip_ctx *c) { return c ? c->err.c_str() : g
 
 const char *vqhip_last_kernel(const vqhip_ctx *c) { return c ? c->last_kernel : "none"; }
 const char *vqhip_last_ranking(const vqhip_ctx *c) { return c ? c->last_ranking : "none"; }
+const char *vqhip_last_projection(const vqhip_ctx *c) { return c ? c->last_projection : "none"; }
 
 const char *vqhip_version(void) { return "vqhip 0.1 (gfx950)"; }
 
@@ -962,6 +967,7 @@ try {
     if (N == 0) return VQHIP_OK;
     c->last_kernel = engine_name(c->engine);
     c->last_ranking = engine_ranking(c->engine);
+    c->last_projection = engine_projection(c->engine);
     // c->noalloc_queue is the device address of `scratch` on this GPU (never the array's name); the launch zeroes it
     HIPCHK(c, engine_assign(c->engine, dX, N, nullptr, Outputs{didx_out, ddist_out, nullptr, nullptr}, (hipStream_t)stream,
                             c->noalloc_queue));

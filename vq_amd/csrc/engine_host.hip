@@ -39,6 +39,7 @@ struct EngineModel {
     int samples_per_batch = 0;
     float ss_limit = 0.0f, wmax2 = 0.0f, mscale = 6.103515625e-05f;
     bool bf = false;                  // k_resident_pipe: screening products on the bf16 matrix cores (mscale is then that path's)
+    bool pj = false;                  // Omega kernels: the projection on the bf16 matrix cores too (img1 = three bf16 pieces per value)
 };
 
 namespace {
@@ -134,17 +135,35 @@ int variant_env()
 // bf16 pieces of the first tiles of a search image, in the layout search_tiles_bf reads (mfma_device.h BF_TILE_BYTES):
 // rows at the f32 tile's pitch; per reduction step q and lane half h the hi pieces of the lane's 8 values (16 bytes), then
 // their lo pieces.  Round to nearest even like v_cvt_pk_bf16_f32; lo = bf16(v - hi) with the difference exact in f32.
+uint16_t to_bf16(float v)                      // round to nearest even, like v_cvt_pk_bf16_f32
+{
+    uint32_t b;
+    std::memcpy(&b, &v, 4);
+    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x40u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+float from_bf16(uint16_t p)
+{
+    const uint32_t b = (uint32_t)p << 16;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+// v = p[0] + p[1] + p[2] (mfma_device.h split3: the remainders are exact in f32)
+void split3_host(float v, uint16_t (&p)[3])
+{
+    p[0] = to_bf16(v);
+    volatile float r = v - from_bf16(p[0]);
+    p[1] = to_bf16(r);
+    volatile float s = r - from_bf16(p[1]);
+    p[2] = to_bf16(s);
+}
+
 template <int R>
 std::vector<float> build_bf_tiles(const std::vector<float> &img, uint32_t nbf)
 {
     using Gm = Geom<R>;
-    auto to_bf16 = [](float v) -> uint16_t {
-        uint32_t b;
-        std::memcpy(&b, &v, 4);
-        if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x40u);
-        b += 0x7FFFu + ((b >> 16) & 1u);
-        return (uint16_t)(b >> 16);
-    };
     std::vector<float> out((size_t)nbf * Gm::W_FLOATS, 0.0f);
     for (uint32_t t = 0; t < nbf; ++t)
         for (int r = 0; r < TILE_ROWS; ++r) {
@@ -419,6 +438,26 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     m.samples_per_batch = 32;
     m.name = "mfma_omega_lds";
     set_bf(m, R);
+    if (m.bf && !getenv("VQHIP_NO_BF_PROJ")) {
+        // the projection on the bf16 matrix cores: piece (step q of 16 reduction values, tile t) at q * NT + t holds, for
+        // lane (row, h), the three bf16 pieces of Omega[32 t + row][16 q + 4 h .. + 3] and [16 q + 8 + 4 h .. + 3]: 1 KiB of
+        // first pieces (16 bytes per lane), 1 KiB of second, 1 KiB of third
+        constexpr int NQ = R / 16;
+        std::vector<uint16_t> pcs((size_t)NQ * NT * 3 * 64 * 8, 0);
+        for (int q = 0; q < NQ; ++q)
+            for (int t = 0; t < NT; ++t)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const uint32_t row = 32u * t + (lane & 31), col = 16u * q + 4u * (lane >> 5) + (e < 4 ? e : e + 4);
+                        if (row >= m.M || col >= m.D) continue;
+                        uint16_t p[3];
+                        split3_host(Om[(size_t)row * m.D + col], p);
+                        for (int c = 0; c < 3; ++c) pcs[((((size_t)q * NT + t) * 3 + c) * 64 + lane) * 8 + e] = p[c];
+                    }
+        img1.assign(pcs.size() / 2, 0.0f);
+        std::memcpy(img1.data(), pcs.data(), pcs.size() * 2);
+        m.pj = true;
+    }
     m.lds_used = (size_t)res_tiles(m.K) * Geom<R>::TILE_BYTES;
     m.search_R = R;
     m.search_img = 2;
@@ -679,6 +718,12 @@ const char *engine_ranking(const EngineModel *m)
     return m->mode == MODE_LOCAL || std::strncmp(m->name, "valu", 4) == 0 ? "none" : "f32";
 }
 
+const char *engine_projection(const EngineModel *m)
+{
+    if (m->pj) return "bf16x6";
+    return m->mode == MODE_EUCLID ? "none" : "f32";
+}
+
 hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out, hipStream_t s, uint32_t *queue)
 {
     if (N == 0) return hipSuccess;
@@ -706,6 +751,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.imgbf = m->imgbf;
     a.nbf = m->imgbf ? m->nbf : 0u;
     a.bfimg = m->bfimg ? 1u : 0u;
+    a.pj = m->pj ? 1u : 0u;
     a.cls = m->cls;
     hipError_t e = m->launch(a, dy != nullptr, s);
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch

@@ -210,12 +210,17 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
 // (engine.h), the search is k_resident_pipe's, distance squared and not rooted (helpers.rs:44).
 // BFIMG: the image of the projected prototypes holds their bf16 pieces (k_resident_pipe's BFIMG): search_pieces, exact
 // rows p_k from the plain matrix in L2.
-template <int R, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false, bool BFIMG = false>
+// PJ: the projection on the bf16 matrix cores as well (mfma_device.h split3 / mma_bf6): Omega comes as three bf16 pieces
+// per value, one 3 KiB piece per (step of 16 reduction values, tile) -- step-major, so a step's sample pieces are split
+// once, serve every tile and are never stored; two tiles' chains run side by side.  y is at least as exact as from the
+// f32 chain (tools/bf16x6_probe.hip) and everything behind it (search, exact re-measurement) works on that y as before.
+template <int R, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false, bool BFIMG = false, bool PJ = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs a)
 {
     using Gs = Geom<R>;
     constexpr int NT = R / 32, NJ = R / 8, NSTEP = NT * NJ;   // Omega tiles, reduction steps per tile, pieces
     constexpr int DEPTH = 6;                                  // Omega pieces in flight per wave
+    constexpr int NQ = R / 16, TG = NT >= 2 ? 2 : 1, NP = NQ * NT, PD = 2 * TG;   // PJ: steps, tiles side by side, pieces, in flight
     __shared__ __attribute__((aligned(16))) char smem[RES_BYTES];
     __shared__ __attribute__((aligned(16))) float mu_lds[R];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -248,10 +253,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     const float *img = (const float *)smem;
     const char *bfimg = smem + ntiles * Gs::TILE_BYTES;
     // Omega pieces: piece i = (tile i / NJ, step i % NJ), this lane's 16 bytes at i * 1024 + lane * 16
-    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, NSTEP * 1024, 0x00020000);
+    // PJ: piece i = (step i / NT, tile i % NT), 3 KiB: the lane's 16 bytes of p1 at i * 3072 + lane * 16, p2 and p3 1 KiB further each
+    const __amdgpu_buffer_rsrc_t rom = __builtin_amdgcn_make_buffer_rsrc((void *)a.img1, 0, PJ ? NP * 3072 : NSTEP * 1024, 0x00020000);
     const uint32_t om_off = (uint32_t)lane * 16u;
     auto piece = [&](int i) {
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, i * 1024, 0));
+    };
+    auto piece3 = [&](int i, u32x4 (&p)[3]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p[c] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rom, om_off, i * 3072 + c * 1024, 0));
     };
 
     // blocks of BLOCK batches per wave: the first fixed, the others claimed a block ahead (BlockQueue)
@@ -294,12 +304,21 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     };
     uint64_t b = block0;
     fetch(b);
+#ifdef VQ_OMEGA_DIAG
+    unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = stamp();
+    const unsigned long long t_begin = tprev_, r_begin = __builtin_amdgcn_s_memrealtime();
+    auto lap = [&](int slot) { const unsigned long long t = stamp(); tm[slot] += t - tprev_; tprev_ = t; };
+#endif
 
     while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
         uint64_t nb0;
         uint32_t nin;
         successor(nb0, nin);
         const uint64_t bnext = nb0 + nin;
+#ifdef VQ_OMEGA_DIAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lap(0);
+#endif
 
         // ---- projection y = Omega x: 32 Omega rows per tile, A fragments from the ring; the accumulators of
         //      tile t are chunks 2(4t + g) + h of y, i.e. fragment entries 4t + g of the search stage
@@ -309,7 +328,39 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
             for (int j = 0; j < R / 8; ++j) xn[j] = mask_chunk(xn[j], (uint32_t)(2 * j + h), a.D);
         }
         if (centred) centre_fragment<R / 8, 2>(xn, mu_lds, h);
-        {
+        if constexpr (PJ) {
+            f32x16 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+            // The ring: PD pieces requested ahead.  (Deeper rings with the loads pinned behind their group -- 2 and 3 groups of
+            // lookahead -- ran at the same 3.95-3.98 ms per 10M rows on one box: the stage is not waiting for L2.)
+            u32x4 ring[PD][3];
+            static_for<0, PD>([&](auto ii) { piece3(decltype(ii)::value, ring[decltype(ii)::value]); });
+            static_for<0, NQ>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                u32x4 xp[3];
+                split24(xn[2 * q], xn[2 * q + 1], xp);
+                static_for<0, NT / TG>([&](auto gg) {
+                    constexpr int i0 = q * NT + decltype(gg)::value * TG;
+                    u32x4 av[TG][3];
+#pragma unroll
+                    for (int u = 0; u < TG; ++u)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) av[u][c] = ring[(i0 + u) % PD][c];
+                    mma_bf6<TG>(av, xp, &acc[decltype(gg)::value * TG]);
+                    static_for<0, TG>([&](auto uu) {
+                        constexpr int i = i0 + decltype(uu)::value;
+                        if constexpr (i + PD < NP) piece3(i + PD, ring[i % PD]);
+                    });
+                });
+            });
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) yf[4 * t + g] = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        } else {
             f32x4 ring[DEPTH];
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) ring[i] = piece(i);
@@ -330,6 +381,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
             });
         }
         const uint32_t label = ln;
+#ifdef VQ_OMEGA_DIAG
+        asm volatile("" : "+v"(yf[0][0]), "+v"(yf[R / 8 - 1][3]));
+        lap(1);
+#endif
         // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
         // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
         asm volatile("" ::: "memory");
@@ -359,6 +414,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
             search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
         }
 
+#ifdef VQ_OMEGA_DIAG
+        lap(2);
+#endif
         Best1 wp, wn;
         if constexpr (BFIMG) finish_keys_g<R, MATCHED, false>(yf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
         else finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
@@ -376,10 +434,23 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
                 if (MATCHED && a.out.dneg) put(a.out.dneg + b * 32, __builtin_bit_cast(uint32_t, wn.d));
             }
         }
+#ifdef VQ_OMEGA_DIAG
+        lap(3);
+#endif
         b = bnext;
         block0 = nb0;
         in_block = nin;
     }
+#ifdef VQ_OMEGA_DIAG
+    if (a.dbg && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+        for (int i = 0; i < 4; ++i) d[i] = tm[i];
+        d[4] = stamp() - t_begin;
+        d[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+        d[6] = r_begin;
+        d[7] = r_begin + d[5];
+    }
+#endif
 }
 
 namespace {
@@ -419,7 +490,28 @@ hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
-    if (a.bf && a.bfimg) {
+    if (a.pj && !a.bf) return hipErrorInvalidValue;                     // built together (bind_omega_pipe)
+    if (a.pj && a.bfimg) {
+        if (a.D < (uint32_t)R) {
+            if (matched)
+                hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true, true, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_omega_pipe<R, false, true, 8, true, true, true>), dim3(grid), dim3(512), 0, st, a);
+        } else if (matched)
+            hipLaunchKernelGGL((k_omega_pipe<R, true, false, 8, true, true, true>), dim3(grid), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_omega_pipe<R, false, false, 8, true, true, true>), dim3(grid), dim3(512), 0, st, a);
+    } else if (a.pj) {
+        if (a.D < (uint32_t)R) {
+            if (matched)
+                hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_omega_pipe<R, false, true, 8, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+        } else if (matched)
+            hipLaunchKernelGGL((k_omega_pipe<R, true, false, 8, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_omega_pipe<R, false, false, 8, true, false, true>), dim3(grid), dim3(512), 0, st, a);
+    } else if (a.bf && a.bfimg) {
         if (a.D < (uint32_t)R) {
             if (matched)
                 hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true, true>), dim3(grid), dim3(512), 0, st, a);

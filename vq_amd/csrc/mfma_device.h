@@ -41,6 +41,7 @@ struct EngineArgs {
     const float *imgbf;       // bf16 pieces of the first nbf tiles of the search image (as many as LDS has room for), or null
     uint32_t nbf;
     uint32_t bfimg;           // the search image itself holds bf16 pieces (every tile); exact rows come from `plain`
+    uint32_t pj;              // Omega kernels: img1 holds Omega as three bf16 pieces per value, the projection runs on the bf16 matrix cores
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
     const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
@@ -769,6 +770,54 @@ __device__ __forceinline__ void split_fragment(const f32x4 (&xf)[R / 8], u32x4 (
 {
 #pragma unroll
     for (int q = 0; q < R / 16; ++q) split8(xf[2 * q], xf[2 * q + 1], bh[q], bl[q]);
+}
+
+// Three pieces: v = p1 + p2 + p3 EXACTLY for a normal f32 (3 x 8 significant bits; the remainders v - p1 and
+// v - p1 - p2 are exact in f32).  The operand form of the projections y = Omega x on the bf16 matrix cores: the six piece
+// products down to 2^-16 of the leading one (p1.p1 | p1.p2, p2.p1 | p1.p3, p2.p2, p3.p1), smallest class first, land
+// within 2^-24-ish of the exact dot product -- measured at or below the error of the v_mfma_f32_32x32x2_f32 chain they
+// replace on every data set tried (tools/bf16x6_probe.hip: 1.7e-7 against 1.7e-7 of |x||w| on uniform data, 8e-7 against
+// 1.1e-6 on one-signed data), at 6 x 32 cycles per 16 reduction values instead of 8 x 64.
+__device__ __forceinline__ void split3(float v0, float v1, uint32_t &p1, uint32_t &p2, uint32_t &p3)
+{
+    p1 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){v0, v1}, bf16x2));
+    const float r0 = v0 - __builtin_bit_cast(float, p1 << 16), r1 = v1 - __builtin_bit_cast(float, p1 & 0xFFFF0000u);
+    p2 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){r0, r1}, bf16x2));
+    const float s0 = r0 - __builtin_bit_cast(float, p2 << 16), s1 = r1 - __builtin_bit_cast(float, p2 & 0xFFFF0000u);
+    p3 = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2v){s0, s1}, bf16x2));
+}
+// the 8 values a lane contributes to one 32x32x16 step (its chunks 2q and 2q + 1, as split8)
+__device__ __forceinline__ void split24(const f32x4 &a0, const f32x4 &a1, u32x4 (&p)[3])
+{
+    uint32_t a[4], b[4], c[4];
+    split3(a0[0], a0[1], a[0], b[0], c[0]);
+    split3(a0[2], a0[3], a[1], b[1], c[1]);
+    split3(a1[0], a1[1], a[2], b[2], c[2]);
+    split3(a1[2], a1[3], a[3], b[3], c[3]);
+    p[0] = u32x4{a[0], a[1], a[2], a[3]};
+    p[1] = u32x4{b[0], b[1], b[2], b[3]};
+    p[2] = u32x4{c[0], c[1], c[2], c[3]};
+}
+__device__ __forceinline__ f32x16 mma_bf(const u32x4 &a, const u32x4 &b, const f32x16 &c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the six products of one step for TG tiles at once (independent chains side by side); a[u] = the weight pieces of tile u
+template <int TG>
+__device__ __forceinline__ void mma_bf6(const u32x4 (&a)[TG][3], const u32x4 (&x)[3], f32x16 *acc)
+{
+#pragma unroll
+    for (int u = 0; u < TG; ++u) acc[u] = mma_bf(a[u][2], x[0], acc[u]);
+#pragma unroll
+    for (int u = 0; u < TG; ++u) acc[u] = mma_bf(a[u][1], x[1], acc[u]);
+#pragma unroll
+    for (int u = 0; u < TG; ++u) acc[u] = mma_bf(a[u][0], x[2], acc[u]);
+#pragma unroll
+    for (int u = 0; u < TG; ++u) acc[u] = mma_bf(a[u][1], x[0], acc[u]);
+#pragma unroll
+    for (int u = 0; u < TG; ++u) acc[u] = mma_bf(a[u][0], x[1], acc[u]);
+#pragma unroll
+    for (int u = 0; u < TG; ++u) acc[u] = mma_bf(a[u][0], x[0], acc[u]);
 }
 
 // tile_mma with the products on the bf16 matrix cores: every split prototype fragment serves the S sample tiles of the wave

@@ -72,6 +72,7 @@ EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, c
 void engine_free(EngineModel *m);
 const char *engine_name(const EngineModel *m);
 const char *engine_ranking(const EngineModel *m);     // "bf16x3" | "f32": where the candidates are ranked; "none": no ranking stage
+const char *engine_projection(const EngineModel *m);  // "bf16x6" | "f32": where y = Omega x is computed; "none": no projection
 // queue: batch counters to use instead of the model's own slots (QUEUE_BYTES of device memory; the launch zeroes
 // them), or null
 hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, const uint32_t *dy, Outputs out,
