@@ -6,7 +6,7 @@ CSRC     := vq_amd/csrc
 # atomic optimizer off: it turns a one-lane returning atomic into atomic + immediate readfirstlane, i.e. a
 # wait for the atomic's round trip right where it is issued (k_resident_pipe claims its batches ahead of time)
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -mllvm -amdgpu-atomic-optimizer-strategy=None -Wall -Wextra -Wno-unused-parameter -Iinclude
-OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_engine.o $(CSRC)/kernels_resident.o $(CSRC)/kernels_omega.o $(CSRC)/kernels_long.o $(CSRC)/kernels_direct.o \
+OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_engine.o $(CSRC)/kernels_resident.o $(CSRC)/kernels_omega.o $(CSRC)/kernels_local.o $(CSRC)/kernels_long.o $(CSRC)/kernels_direct.o \
             $(CSRC)/kernels_project.o $(CSRC)/engine_host.o $(CSRC)/synth.o
 HDRS     := $(CSRC)/vq_common.h $(CSRC)/engine.h $(CSRC)/mfma_device.h $(CSRC)/mfma_host.h $(CSRC)/mfma_images.h include/vqhip.h
 LIB      := vq_amd/libvqhip.so

@@ -47,7 +47,7 @@ PEAK_HBM_GBS = 8000.0            # spec; ~6300 achievable
 KERNEL_FN = {"mfma_euclid_lds_pipe": "k_resident_pipe", "mfma_euclid_lds_staged": "k_resident_pipe",
              "mfma_euclid_lds_pipe_cut": "k_resident_pipe", "mfma_euclid_lds": "k_resident", "mfma_omega_lds": "k_omega_pipe",
              "mfma_omega_lowrank_lds": "k_lowrank_pipe", "mfma_euclid_long": "k_long", "mfma_omega_long": "k_omega_long",
-             "mfma_local_long": "k_local_long", "valu_euclid_direct": "k_direct", "scalar": "k_assign_scalar"}
+             "mfma_local_long": "k_local_long", "mfma_local_bf16": "k_local_pj", "valu_euclid_direct": "k_direct", "scalar": "k_assign_scalar"}
 HBM_BOUND = {"c2k32", "c2k8"}    # few prototypes: the memory pipe binds, not the matrix pipe
 
 

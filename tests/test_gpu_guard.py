@@ -156,7 +156,7 @@ OFFSET_MODELS = [
     ("gmlvq_128", 128, 256, 128, "global", "mfma_omega_lds"),
     ("liramlvq_16x256", 256, 1024, 16, "global", "mfma_omega_lowrank_lds"),
     ("gmlvq_k600_streamed", 128, 600, 128, "global", "mfma_omega"),
-    ("lgmlvq_8x64", 64, 8, 64, "local", "mfma_local"),
+    ("lgmlvq_8x64", 64, 8, 64, "local", "mfma_local_bf16"),
 ]
 
 

@@ -103,9 +103,9 @@ SHAPES = [
 AUTO_KERNEL = {
     "c1_vq_iris_shape": "valu_euclid_direct", "glvq_128x256": "mfma_euclid", "glvq_ragged_d100_k37": "mfma_euclid",
     "glvq_d64_k70": "mfma_euclid", "glvq_streamed_k600": "mfma_euclid", "glvq_streamed_d256": "mfma_euclid", "gmlvq_128x128": "mfma_omega", "gmlvq_small_d12": "mfma_omega",
-    "liramlvq_r16_d256": "mfma_omega", "liramlvq_r3_d20": "mfma_omega", "lgmlvq_8x128": "mfma_local",
+    "liramlvq_r16_d256": "mfma_omega", "liramlvq_r3_d20": "mfma_omega", "lgmlvq_8x128": "mfma_local_bf16",
     "lgmlvq_small": "mfma_local",  # D = 10: rows only 4-byte aligned, cut at D inside the kernel
-    "c4_liramlvq_r16_d256_k1024": "mfma_omega_lowrank_lds", "c5_lgmlvq_64x128x128": "mfma_local",
+    "c4_liramlvq_r16_d256_k1024": "mfma_omega_lowrank_lds", "c5_lgmlvq_64x128x128": "mfma_local_bf16",
 }
 
 
@@ -821,7 +821,7 @@ def test_euclid_and_local_dispatch_grids(ctx):
                     ctx.set_local_omegas(Oms)
                 seen.add(_auto_vs_scalar(ctx, Xd, N, load, (D, M, K), "mfma_local"))
     ctx.set_kernel_policy(KERNEL_AUTO)
-    assert {"valu_euclid_direct", "mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local", "mfma_local_long"} <= seen, seen
+    assert {"valu_euclid_direct", "mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local", "mfma_local_bf16", "mfma_local_long"} <= seen, seen
 
 
 def test_matched_dispatch_grid(ctx):

@@ -25,7 +25,7 @@ MODELS = [
     ("glvq_long_rows", 300, 50, 0, "none", "mfma_euclid_long"),
     ("gmlvq_c3_shape", 128, 256, 128, "global", "mfma_omega_lds"),
     ("liramlvq_c4_shape", 256, 1024, 16, "global", "mfma_omega_lowrank_lds"),
-    ("lgmlvq_local", 128, 8, 128, "local", "mfma_local"),
+    ("lgmlvq_local", 128, 8, 128, "local", "mfma_local_bf16"),
 ]
 
 

@@ -42,4 +42,20 @@ struct Geom {
     __host__ __device__ static constexpr int chunk_off(int row, int c) { return row * ROW_FLOATS + c * 4; }
 };
 
+// Tiles whose weights are stored as three bf16 pieces per value (v = p1 + p2 + p3 exactly: mfma_device.h split3), the
+// A operand of v_mfma_f32_32x32x16_bf16: per row, per step q of 16 reduction values and lane half h, 16 bytes of first
+// pieces, 16 of second, 16 of third, for the row's values 16 q + 4 h .. + 3 and 16 q + 8 + 4 h .. + 3.  Rows are padded
+// by 16 bytes like Geom's (consecutive rows start 4 banks apart); the tail is Geom's (32 init values, 32 class ids).
+template <int R>
+struct Geom3 {
+    static_assert(R >= 16 && R <= 256 && (R & (R - 1)) == 0, "reduction length: power of two in [16, 256]");
+    static constexpr int NQ = R / 16;
+    static constexpr int ROW_BYTES = NQ * 96 + 16;
+    static constexpr int W_BYTES = TILE_ROWS * ROW_BYTES;
+    static constexpr int TILE_BYTES = W_BYTES + TAIL_BYTES;
+    static constexpr int G = Geom<R>::G;                       // tiles per LDS stage
+    static constexpr int STAGE_BYTES = G * TILE_BYTES;
+    __host__ __device__ static constexpr int piece_off(int row, int q, int h, int c) { return row * ROW_BYTES + q * 96 + h * 48 + c * 16; }
+};
+
 }  // namespace vq

@@ -505,6 +505,56 @@ bool bind_local_long(EngineModel &m, std::vector<float> &img1, std::vector<float
     return true;
 }
 
+// LGMLVQ with the projections on the bf16 matrix cores: k_local_pj (kernels_local.hip).  Every Omega_j padded to whole
+// 32-row tiles as in bind_local; the tiles are Geom3 tiles (engine.h): three bf16 pieces per weight, Geom's tail.
+template <int R1>
+bool bind_local_pj(EngineModel &m, std::vector<float> &img, const std::vector<float> &Oms, const std::vector<float> &negp,
+                   const std::vector<uint32_t> &cls)
+{
+    using G3 = Geom3<R1>;
+    if (m.R1 != (uint32_t)R1 || getenv("VQHIP_NO_BF") || getenv("VQHIP_NO_BF_PROJ")) return false;
+    int spb = 0;
+    const LaunchFn fn = local_pj_launcher(R1, &spb);
+    if (!fn) return false;
+    const uint32_t tpp = (m.M + 31) / 32;
+    const size_t tiles = (size_t)m.K * tpp, ngroups = (tiles + G3::G - 1) / G3::G;
+    std::vector<unsigned char> bytes(ngroups * G3::STAGE_BYTES, 0);
+    for (size_t t = 0; t < ngroups * G3::G; ++t) {
+        unsigned char *tile = bytes.data() + t * G3::TILE_BYTES;
+        float *tail = reinterpret_cast<float *>(tile + G3::W_BYTES);
+        const size_t j = t / tpp;
+        for (int r = 0; r < 32; ++r) {
+            const uint32_t row = 32u * (uint32_t)(t % tpp) + r;
+            uint32_t c = 0xFFFFFFFFu;
+            if (j < m.K) {
+                if (row < m.M) {
+                    const float *src = &Oms[((size_t)j * m.M + row) * m.D];
+                    for (uint32_t d = 0; d < m.D; ++d) {
+                        // value d of the row: step d / 16, lane half (d / 4) & 1, element (d & 3) + 4 ((d / 8) & 1)
+                        uint16_t p[3];
+                        split3_host(src[d], p);
+                        const int q = d / 16, hh = (d / 4) & 1, e = (d & 3) + 4 * ((d / 8) & 1);
+                        for (int cc = 0; cc < 3; ++cc)
+                            std::memcpy(tile + G3::piece_off(r, q, hh, cc) + 2 * e, &p[cc], 2);
+                    }
+                    tail[r] = negp[j * m.M + row];
+                }
+                if (!cls.empty()) c = cls[j];
+            }
+            std::memcpy(&tail[32 + r], &c, 4);
+        }
+    }
+    img.assign(bytes.size() / 4, 0.0f);
+    std::memcpy(img.data(), bytes.data(), bytes.size());
+    m.ngroups1 = (uint32_t)ngroups;
+    m.tiles_per_proto = tpp;
+    m.launch = fn;
+    m.samples_per_batch = spb;
+    m.name = "mfma_local_bf16";
+    m.pj = true;
+    return true;
+}
+
 template <int R1>
 bool bind_local(EngineModel &m, std::vector<float> &img, const std::vector<float> &Oms, const std::vector<float> &negp,
                 const std::vector<uint32_t> &cls)
@@ -647,7 +697,8 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
                     t += (double)Om[((size_t)j * M + r) * D + d] * (double)W[(size_t)j * D + d];
                 negp[(size_t)j * M + r] = (float)(-t);
             }
-        ok = bind_local_long(m, img1, img2, Om, negp) || bind_local<16>(m, img1, Om, negp, cls) || bind_local<32>(m, img1, Om, negp, cls) ||
+        ok = bind_local_long(m, img1, img2, Om, negp) || bind_local_pj<64>(m, img1, Om, negp, cls) || bind_local_pj<128>(m, img1, Om, negp, cls) ||
+             bind_local<16>(m, img1, Om, negp, cls) || bind_local<32>(m, img1, Om, negp, cls) ||
              bind_local<64>(m, img1, Om, negp, cls) || bind_local<128>(m, img1, Om, negp, cls) ||
              bind_local<256>(m, img1, Om, negp, cls);
     }

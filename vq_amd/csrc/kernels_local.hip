@@ -1,0 +1,234 @@
+// LGMLVQ (src/lgmlvq/lgmlvq.rs:436-506) with the projections on the bf16 matrix cores: k_local_pj.
+//
+// The distance of sample x to prototype j is ||Omega_j x - Omega_j w_j||^2 with a matrix of its own per prototype, so
+// the whole job is projections -- k_engine<MODE_LOCAL> runs them on v_mfma_f32_32x32x2_f32 at 0.9 of that pipe's peak
+// and that is where it ends.  Here Omega_j and x are each split into three bf16 pieces that add up to the f32 value
+// exactly, and the six piece products down to 2^-16 of the leading one run on v_mfma_f32_32x32x16_bf16 with f32
+// accumulation (mfma_device.h split3): 6 x 32 cycles per 16 reduction values instead of 8 x 64, and a result measured
+// at or below the f32 chain's error (tools/bf16x6_probe.hip).
+//
+// Same skeleton as k_engine: a workgroup of 4 waves walks the stream of Omega_j tiles through a double-buffered LDS
+// stage filled by LDS-DMA, one barrier per stage; batches are claimed from a counter.  What differs:
+//   * the tiles are Geom3 tiles (engine.h): 6 bytes per weight, read as three ds_read_b128 per step;
+//   * a wave holds S = 3 tiles of 32 samples as PIECES (288 registers) -- one workgroup per CU, one wave per SIMD, the
+//     whole register file; the three samples' chains are independent, which is what keeps the matrix pipe fed by a
+//     single wave -- so a staged tile (25 KiB for 128 values) serves 384 samples, and the stream of all Omega_j (6.5 MB
+//     for config 5, more than an XCD's L2 holds) stays near 2 TB/s chip-wide;
+//   * the sample rows are dead once split, and are fetched again for the next batch behind the last tile.
+#include <cstdlib>
+
+#include "mfma_device.h"
+
+namespace vq {
+
+// acc[s] = init column + tile . x[s]^T for one Geom3 tile in LDS (rows = the tile's 32 Omega_j rows, column = sample)
+template <int R, int S>
+__device__ __forceinline__ void tile_mma_pj(const char *tile, const u32x4 (&xp)[S][R / 16][3], f32x16 (&acc)[S], int row, int h)
+{
+    using G3 = Geom3<R>;
+    const float *tail = (const float *)(tile + G3::W_BYTES);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
+            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
+        }
+    }
+    const char *rowp = tile + G3::piece_off(row, 0, h, 0);
+    u32x4 an[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) an[c] = *(const u32x4 *)(rowp + 16 * c);
+    static_for<0, R / 16>([&](auto qq) {
+        constexpr int q = decltype(qq)::value;
+        u32x4 av[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) av[c] = an[c];
+        if constexpr (q + 1 < R / 16) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) an[c] = *(const u32x4 *)(rowp + 96 * (q + 1) + 16 * c);
+        }
+        // smallest class of products first; the S chains side by side
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[2], xp[s][q][0], acc[s]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[1], xp[s][q][1], acc[s]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[0], xp[s][q][2], acc[s]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[1], xp[s][q][0], acc[s]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[0], xp[s][q][1], acc[s]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[0], xp[s][q][0], acc[s]);
+    });
+}
+
+template <int R1, int S, bool MATCHED>
+__global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
+{
+    using G3 = Geom3<R1>;
+    constexpr int NQ = R1 / 16;
+    __shared__ __attribute__((aligned(16))) char smem[2 * G3::STAGE_BYTES];
+    __shared__ uint32_t claimed;                                     // the batch after this one
+    __shared__ __attribute__((aligned(16))) float mu_lds[R1];
+    stage_centre<R1>(mu_lds, a.mu, threadIdx.x, 256);                // published by the first barrier below
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s_col = lane & 31, h = lane >> 5;
+    const uint32_t ngroups = a.ngroups1;
+
+    auto issue = [&](uint32_t q, int buf) {                          // stage q of the cyclic stream of Omega_j tiles
+        stage_group<G3::STAGE_BYTES>(smem + buf * G3::STAGE_BYTES, (const char *)a.img1 + (size_t)q * G3::STAGE_BYTES, wave, lane);
+    };
+
+    // this wave's S tiles of 32 samples of batch bb, straight from HBM through a range-checked buffer descriptor
+    // (k_engine's load_samples)
+    f32x4 xf[S][R1 / 8];
+    uint32_t label[S];
+    const uint32_t row_bytes = a.D * 4u;
+    const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    auto load_samples = [&](uint64_t bb) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint64_t first = ((bb * 4 + wave_u) * S + s) * 32;
+            uint32_t rec = 0u, rec_y = 0u;
+            if (bb < a.nbatches && first < a.N) {
+                const uint64_t left = a.N - first;
+                rec = left * row_bytes > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * row_bytes);
+                rec_y = left * 4u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(left * 4u);
+            }
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + first * a.D), 0, (int)rec, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < R1 / 8; ++j)
+                xf[s][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff + j * 32, 0, 0));
+            if (MATCHED) {
+                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)(a.y + first), 0, (int)rec_y, 0x00020000);
+                label[s] = __builtin_amdgcn_raw_buffer_load_b32(ry, (uint32_t)s_col * 4u, 0, 0);
+            } else {
+                label[s] = 0u;
+            }
+        }
+    };
+
+    int cur = 0;
+    uint64_t b = blockIdx.x;
+    if (b < a.nbatches) {
+        issue(0, 0);
+        load_samples(b);
+        __syncthreads();                                             // waits vmcnt(0) for the DMA, then barrier
+    }
+
+    // thread 0 keeps one claim in flight: the atomic issued at the top of batch k returns batch k + 2
+    uint32_t pending = 0u;
+    if (tid == 0) pending = gridDim.x + atomicAdd(a.queue, 1u);
+
+    while (b < a.nbatches) {
+        if (tid == 0) {
+            claimed = pending;                                       // the wait for the atomic of a batch ago is here
+            pending = gridDim.x + atomicAdd(a.queue, 1u);
+        }
+        __syncthreads();
+        const uint64_t bnext = claimed;
+        // rows -> pieces: D < R1 cut (0 x INF is NaN), the model's centre subtracted, three bf16 pieces per value
+        u32x4 xp[S][NQ][3];
+        uint64_t sample[S];
+        uint32_t lab[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (a.D < (uint32_t)R1) {
+#pragma unroll
+                for (int j = 0; j < R1 / 8; ++j) xf[s][j] = mask_chunk(xf[s][j], (uint32_t)(2 * j + h), a.D);
+            }
+            if (a.mu != nullptr) centre_fragment<R1 / 8, 2>(xf[s], mu_lds, h);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) split24(xf[s][2 * q], xf[s][2 * q + 1], xp[s][q]);
+            sample[s] = ((b * 4 + wave) * S + s) * 32 + s_col;
+            lab[s] = label[s];
+        }
+
+        Best1 pos[S], neg[S];                                         // exact distances, offered in index order
+        float dsum[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) dsum[s] = 0.0f;
+
+        for (uint32_t q = 0; q < ngroups; ++q) {
+            // prefetch the next stage (nothing to stage after the last batch), compute on this one, barrier
+            const bool wrap = q + 1 == ngroups;
+            if (!(wrap && bnext >= a.nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);
+            const char *stage = smem + cur * G3::STAGE_BYTES;
+            // ---- z = Omega_j x - Omega_j w_j (accumulator starts at -p_j), ||z||^2 summed per prototype
+#pragma unroll
+            for (int tt = 0; tt < G3::G; ++tt) {
+                const char *tile = stage + tt * G3::TILE_BYTES;
+                f32x16 acc[S];
+                tile_mma_pj<R1, S>(tile, xp, acc, s_col, h);
+                const uint32_t ti = q * G3::G + tt;
+                const uint32_t j = ti / a.tiles_per_proto, t = ti % a.tiles_per_proto;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dsum[s] = fmaf(acc[s][r], acc[s][r], dsum[s]);
+                if (t + 1 == a.tiles_per_proto) {
+                    const uint32_t cj = ((const uint32_t *)(tile + G3::W_BYTES))[32];
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const float total = dsum[s] + xor32(dsum[s]);
+                        dsum[s] = 0.0f;
+                        if (j < a.K) {                                // pad tiles past the last prototype never compete
+                            if (!MATCHED || cj == lab[s]) pos[s].offer(total, j);   // lgmlvq.rs:448 / :487
+                            else neg[s].offer(total, j);                             // lgmlvq.rs:496
+                        }
+                    }
+                }
+            }
+            __syncthreads();               // next stage landed (vmcnt(0)) and everyone is done reading this one
+            cur ^= 1;
+        }
+
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (sample[s] < a.N) {
+                if (h == 0) {
+                    if (a.out.idx) a.out.idx[sample[s]] = pos[s].i;
+                    if (MATCHED && a.out.jneg) a.out.jneg[sample[s]] = neg[s].i;
+                } else {
+                    if (a.out.dist) a.out.dist[sample[s]] = pos[s].d;
+                    if (MATCHED && a.out.dneg) a.out.dneg[sample[s]] = neg[s].d;
+                }
+            }
+        }
+        load_samples(bnext);
+        b = bnext;
+    }
+}
+
+namespace {
+template <int R1, int S>
+hipError_t launch_local_pj(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const unsigned grid = (unsigned)(a.nbatches < 256 ? a.nbatches : 256);      // one workgroup per CU
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    if (matched)
+        hipLaunchKernelGGL((k_local_pj<R1, S, true>), dim3(grid), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_local_pj<R1, S, false>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn local_pj_launcher(int R1, int *samples_per_batch)
+{
+    constexpr int S = 3;
+    *samples_per_batch = 4 * S * 32;                                  // 4 waves x S tiles x 32 samples
+    switch (R1) {
+    case 64: return &launch_local_pj<64, S>;
+    case 128: return &launch_local_pj<128, S>;
+    default: return nullptr;
+    }
+}
+
+}  // namespace vq
