@@ -459,10 +459,10 @@ def run_rank(args):
         del X, idx_buf, dst_buf
         torch.cuda.empty_cache()
         line["extra"] = {}
-        # c2_f32 / c3_f32: the same workloads with the candidates ranked on the f32 matrix cores (VQHIP_NO_BF, read when the
+        # c2_f32 / c3_f32 / c5_f32: the same workloads with everything on the f32 matrix cores (VQHIP_NO_BF, read when the
         # model's images are built): the kernels the f32-MFMA fractions of DESIGN.md section 5 are quoted on
         for name, xrows in (("c3", 10_000_000), ("c4", 10_000_000), ("c5", 4_000_000), ("c2k32", 10_000_000), ("c2k8", 10_000_000),
-                            ("c2_f32", 10_000_000), ("c3_f32", 10_000_000)):
+                            ("c2_f32", 10_000_000), ("c3_f32", 10_000_000), ("c5_f32", 4_000_000)):
             f32_only = name.endswith("_f32")
             xc = synth.CONFIGS[name[:-4] if f32_only else name]
             xm = synth.make_model(xc)
@@ -478,7 +478,7 @@ def run_rank(args):
                 ctx.assign_into(Xx, xi, xd)
             torch.cuda.synchronize(dev)
             evs = []
-            n_launch = 20 if name != "c5" else 10
+            n_launch = 20 if not name.startswith("c5") else 10
             tw = time.perf_counter()
             for _ in range(n_launch):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
