@@ -113,6 +113,14 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
         }
     };
 
+#ifdef VQ_LOCAL_DIAG      // phase stamps and the in-kernel clock (engine_assign prints them: VQHIP_VARIANT=35 VQHIP_DUMP=1 VQHIP_NW4=1)
+    const unsigned long long t_begin = stamp(), r_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = t_begin;
+    auto lap = [&](int slot) { const unsigned long long t = stamp(); tm[slot] += t - tprev_; tprev_ = t; };
+#define VQ_LAP(i) lap(i)
+#else
+#define VQ_LAP(i)
+#endif
     int cur = 0;
     uint64_t b = blockIdx.x;
     if (b < a.nbatches) {
@@ -157,7 +165,9 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
         for (uint32_t q = 0; q < ngroups; ++q) {
             // prefetch the next stage (nothing to stage after the last batch), compute on this one, barrier
             const bool wrap = q + 1 == ngroups;
+            VQ_LAP(3);                     // 3: everything outside the stage loop's three phases
             if (!(wrap && bnext >= a.nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);
+            VQ_LAP(0);                     // 0: issue of the next stage's DMA
             const char *stage = smem + cur * G3::STAGE_BYTES;
             // ---- z = Omega_j x - Omega_j w_j (accumulator starts at -p_j), ||z||^2 summed per prototype
 #pragma unroll
@@ -165,6 +175,10 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
                 const char *tile = stage + tt * G3::TILE_BYTES;
                 f32x16 acc[S];
                 tile_mma_pj<R1, S>(tile, xp, acc, s_col, h);
+#ifdef VQ_LOCAL_DIAG
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[S - 1]));
+#endif
+                VQ_LAP(1);                 // 1: the tile's MFMAs
                 const uint32_t ti = q * G3::G + tt;
                 const uint32_t j = ti / a.tiles_per_proto, t = ti % a.tiles_per_proto;
 #pragma unroll
@@ -184,6 +198,7 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
                     }
                 }
             }
+            VQ_LAP(2);                     // 2: squared norms, offers
             __syncthreads();               // next stage landed (vmcnt(0)) and everyone is done reading this one
             cur ^= 1;
         }
@@ -203,6 +218,16 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
         load_samples(bnext);
         b = bnext;
     }
+#ifdef VQ_LOCAL_DIAG
+    if (a.dbg && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 4; ++i) d[i] = tm[i];
+        d[4] = stamp() - t_begin;
+        d[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+        d[6] = r_begin;
+        d[7] = r_begin + d[5];
+    }
+#endif
 }
 
 namespace {
