@@ -75,6 +75,32 @@ int main()
         mu.clear();
         CHECK(!centre_prototypes(Wn, 64, 20, mu, Wc));
     }
+    // ---- three bf16 pieces add up to the f32 value exactly (normal numbers; what the bf16x6 projections rest on)
+    {
+        const std::vector<float> v = uniform(20000, 77, -3.0f, 3.0f);
+        for (size_t i = 0; i < v.size(); ++i) {
+            const float x = i % 3 == 0 ? v[i] * 1e-20f : i % 3 == 1 ? v[i] * 1e20f : v[i];
+            uint16_t pc[3];
+            split3_host(x, pc);
+            CHECK((double)from_bf16(pc[0]) + (double)from_bf16(pc[1]) + (double)from_bf16(pc[2]) == (double)x);
+        }
+        // k_omega_pipe's Omega pieces: piece (q, t), class c, lane, element e
+        EngineModel o;
+        o.K = 40; o.D = 100; o.M = 70;
+        o.R1 = 128; o.R2 = 128;
+        const std::vector<float> Om = uniform((size_t)o.M * o.D, 5), P = uniform((size_t)o.K * o.M, 6);
+        std::vector<float> norms(o.K, 1.0f), a, b;
+        std::vector<uint32_t> none;
+        CHECK(bind_omega_pipe<128>(o, a, b, Om, P, norms, none) && o.pj && a.size() * 4 == (size_t)8 * 4 * 3072);
+        const uint16_t *pcs = reinterpret_cast<const uint16_t *>(a.data());
+        for (uint32_t row = 0; row < 128; row += 3)
+            for (uint32_t col = 0; col < 128; col += 7) {
+                const int q = col / 16, t = row / 32, lane = (row % 32) + 32 * ((col / 4) & 1), e = (col & 3) + 4 * ((col / 8) & 1);
+                double sum = 0.0;
+                for (int c = 0; c < 3; ++c) sum += (double)from_bf16(pcs[((((size_t)q * 4 + t) * 3 + c) * 64 + lane) * 8 + e]);
+                CHECK(sum == (row < o.M && col < o.D ? (double)Om[(size_t)row * o.D + col] : 0.0));
+            }
+    }
     // ---- every image builder over shapes around its boundaries
     const uint32_t Ds[] = {1, 3, 16, 31, 64, 100, 128, 200, 256, 257, 784};
     const uint32_t Ks[] = {1, 2, 8, 9, 33, 256, 1000};
@@ -115,9 +141,32 @@ int main()
                     l.K = K; l.D = D; l.M = M;
                     l.R1 = o.R1;
                     std::vector<float> c, d;
-                    ok = bind_local_long(l, c, d, Oms, negp) || bind_local<16>(l, c, Oms, negp, cls) || bind_local<32>(l, c, Oms, negp, cls) ||
+                    ok = bind_local_long(l, c, d, Oms, negp) || bind_local_pj<64>(l, c, Oms, negp, cls) || bind_local_pj<128>(l, c, Oms, negp, cls) ||
+                         bind_local<16>(l, c, Oms, negp, cls) || bind_local<32>(l, c, Oms, negp, cls) ||
                          bind_local<64>(l, c, Oms, negp, cls) || bind_local<128>(l, c, Oms, negp, cls) || bind_local<256>(l, c, Oms, negp, cls);
                     CHECK(ok && !c.empty());
+                    CHECK(l.pj == (D > 32 && D <= 128));
+                    if (l.pj && D > 64) {       // Geom3 tiles: the three pieces of every weight add up to it exactly, tails in place
+                        using G3 = Geom3<128>;
+                        const uint32_t tpp = (M + 31) / 32;
+                        CHECK(c.size() * 4 == (size_t)l.ngroups1 * G3::STAGE_BYTES && l.ngroups1 == K * tpp && l.samples_per_batch == 384);
+                        const unsigned char *bytes = reinterpret_cast<const unsigned char *>(c.data());
+                        for (uint32_t j = 0; j < K; ++j)
+                            for (uint32_t r = 0; r < M; r += 7)
+                                for (uint32_t dd = 0; dd < D; dd += 5) {
+                                    const unsigned char *tile = bytes + ((size_t)j * tpp + r / 32) * G3::TILE_BYTES;
+                                    double sum = 0.0;
+                                    for (int cc = 0; cc < 3; ++cc) {
+                                        uint16_t pc;
+                                        std::memcpy(&pc, tile + G3::piece_off((int)(r % 32), (int)(dd / 16), (int)((dd / 4) & 1), cc) + 2 * ((dd & 3) + 4 * ((dd / 8) & 1)), 2);
+                                        sum += (double)from_bf16(pc);
+                                    }
+                                    CHECK(sum == (double)Oms[((size_t)j * M + r) * D + dd]);
+                                    float init;
+                                    std::memcpy(&init, tile + G3::W_BYTES + 4 * (r % 32), 4);
+                                    CHECK(init == negp[(size_t)j * M + r]);
+                                }
+                    }
                 }
             }
         }
