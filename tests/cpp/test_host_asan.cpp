@@ -24,7 +24,7 @@ LaunchFn direct_launcher(int R, int KP, int *spb) { *spb = 64; return pow2_in(R,
 LaunchFn long_launcher(int tiles) { return tiles == 1 || tiles == 2 || tiles == 4 || tiles == 8 ? &no_device : nullptr; }
 LaunchFn local_long_launcher(int tiles) { return tiles == 1 || tiles == 2 || tiles == 4 ? &no_device : nullptr; }
 LaunchFn omega_long_launcher(int R2) { return pow2_in(R2, 32, 128) ? &no_device : nullptr; }
-LaunchFn local_pj_launcher(int R1, int *spb) { *spb = 384; return pow2_in(R1, 64, 128) ? &no_device : nullptr; }
+LaunchFn local_pj_launcher(int R1, int *spb) { *spb = R1 == 256 ? 256 : 384; return pow2_in(R1, 16, 256) ? &no_device : nullptr; }
 }  // namespace vq
 
 namespace {
@@ -141,12 +141,13 @@ int main()
                     l.K = K; l.D = D; l.M = M;
                     l.R1 = o.R1;
                     std::vector<float> c, d;
-                    ok = bind_local_long(l, c, d, Oms, negp) || bind_local_pj<64>(l, c, Oms, negp, cls) || bind_local_pj<128>(l, c, Oms, negp, cls) ||
+                    ok = bind_local_long(l, c, d, Oms, negp) || bind_local_pj<16>(l, c, Oms, negp, cls) || bind_local_pj<32>(l, c, Oms, negp, cls) ||
+                         bind_local_pj<64>(l, c, Oms, negp, cls) || bind_local_pj<128>(l, c, Oms, negp, cls) || bind_local_pj<256>(l, c, Oms, negp, cls) ||
                          bind_local<16>(l, c, Oms, negp, cls) || bind_local<32>(l, c, Oms, negp, cls) ||
                          bind_local<64>(l, c, Oms, negp, cls) || bind_local<128>(l, c, Oms, negp, cls) || bind_local<256>(l, c, Oms, negp, cls);
                     CHECK(ok && !c.empty());
-                    CHECK(l.pj == (D > 32 && D <= 128));
-                    if (l.pj && D > 64) {       // Geom3 tiles: the three pieces of every weight add up to it exactly, tails in place
+                    CHECK(l.pj == (D <= 256));
+                    if (l.pj && D > 64 && D <= 128) {       // Geom3 tiles: the three pieces of every weight add up to it exactly, tails in place
                         using G3 = Geom3<128>;
                         const uint32_t tpp = (M + 31) / 32;
                         CHECK(c.size() * 4 == (size_t)l.ngroups1 * G3::STAGE_BYTES && l.ngroups1 == K * tpp && l.samples_per_batch == 384);

@@ -821,7 +821,7 @@ def test_euclid_and_local_dispatch_grids(ctx):
                     ctx.set_local_omegas(Oms)
                 seen.add(_auto_vs_scalar(ctx, Xd, N, load, (D, M, K), "mfma_local"))
     ctx.set_kernel_policy(KERNEL_AUTO)
-    assert {"valu_euclid_direct", "mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local", "mfma_local_bf16", "mfma_local_long"} <= seen, seen
+    assert {"valu_euclid_direct", "mfma_euclid", "mfma_euclid_lds", "mfma_euclid_lds_pipe", "mfma_euclid_long", "mfma_local_bf16", "mfma_local_long"} <= seen, seen
 
 
 def test_matched_dispatch_grid(ctx):

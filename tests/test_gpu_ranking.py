@@ -120,3 +120,52 @@ def test_bf16_ranking_returns_the_f32_rankings_results(shape, kind):
     assert rep.ok, str(rep)
     if kind == "grid" and not M:
         assert rep.mismatches == 0, str(rep)
+
+
+LOCAL_SHAPES = [(128, 8, 128), (64, 8, 64), (256, 5, 40), (200, 3, 33), (32, 16, 32), (10, 5, 10)]
+
+
+@pytest.mark.parametrize("shape", LOCAL_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_local_projection_on_the_bf16_cores_against_the_f32_engine(shape):
+    """LGMLVQ (src/lgmlvq/lgmlvq.rs:436-506): k_local_pj (six bf16 piece products per product) against k_engine<LOCAL> (f32 MFMA,
+    VQHIP_NO_BF_PROJ) on the same model -- distances to rounding, winners up to near-ties -- and both against the f64 oracle."""
+    D, K, M = shape
+    rng = np.random.default_rng(zlib.crc32(f"local-{D}-{K}-{M}".encode()))
+    N = 2500
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    Oms = (rng.uniform(-1, 1, size=(K, M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            ctx = Context(0)
+            ctx.set_kernel_policy(KERNEL_AUTO)
+            ctx.set_prototypes(W)
+            ctx.set_local_omegas(Oms)
+            idx, dist = ctx.assign(X)
+            out = (ctx.last_kernel, ctx.last_projection, idx, dist)
+            ctx.set_labels(cls)
+            out += (ctx.assign_matched(X, y),)
+            ctx.close()
+            return out
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+    kb, pb, ib, db, mb = run({})
+    kf, pf, i32, d32, m32 = run({"VQHIP_NO_BF_PROJ": "1"})
+    assert (kb, pb) == ("mfma_local_bf16", "bf16x6") and (kf, pf) == ("mfma_local", "f32"), (kb, pb, kf, pf)
+    for j, d, fj, fd in ((ib, db, i32, d32), (mb[0], mb[1], m32[0], m32[1]), (mb[2], mb[3], m32[2], m32[3])):
+        d, fd = np.asarray(d, dtype=np.float64), np.asarray(fd, dtype=np.float64)
+        fin = np.isfinite(fd)
+        assert np.array_equal(np.isfinite(d), fin)
+        assert np.all(np.abs(d[fin] - fd[fin]) <= 2e-5 * np.abs(fd[fin]) + 2e-6), float(np.abs(d[fin] - fd[fin]).max())
+        assert int((np.asarray(j) != np.asarray(fj)).sum()) <= 2
+    sel = slice(0, 500)
+    for idx, dist in ((ib, db), (i32, d32)):
+        rep = parity.compare(idx[sel], dist[sel], *oracle.assign(X[sel], W, omega=Oms, threads=8), atol=2e-6)
+        print(shape, rep)
+        assert rep.ok and rep.floor_used == 0, str(rep)

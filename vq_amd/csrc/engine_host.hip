@@ -697,7 +697,8 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
                     t += (double)Om[((size_t)j * M + r) * D + d] * (double)W[(size_t)j * D + d];
                 negp[(size_t)j * M + r] = (float)(-t);
             }
-        ok = bind_local_long(m, img1, img2, Om, negp) || bind_local_pj<64>(m, img1, Om, negp, cls) || bind_local_pj<128>(m, img1, Om, negp, cls) ||
+        ok = bind_local_long(m, img1, img2, Om, negp) || bind_local_pj<16>(m, img1, Om, negp, cls) || bind_local_pj<32>(m, img1, Om, negp, cls) || bind_local_pj<64>(m, img1, Om, negp, cls) ||
+             bind_local_pj<128>(m, img1, Om, negp, cls) || bind_local_pj<256>(m, img1, Om, negp, cls) ||
              bind_local<16>(m, img1, Om, negp, cls) || bind_local<32>(m, img1, Om, negp, cls) ||
              bind_local<64>(m, img1, Om, negp, cls) || bind_local<128>(m, img1, Om, negp, cls) ||
              bind_local<256>(m, img1, Om, negp, cls);

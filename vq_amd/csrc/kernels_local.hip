@@ -247,11 +247,15 @@ hipError_t launch_local_pj(const EngineArgs &a, bool matched, hipStream_t st)
 
 LaunchFn local_pj_launcher(int R1, int *samples_per_batch)
 {
-    constexpr int S = 3;
+    // S sample tiles per wave as pieces: 12 S registers per 16 values of a row
+    const int S = R1 == 256 ? 2 : 3;
     *samples_per_batch = 4 * S * 32;                                  // 4 waves x S tiles x 32 samples
     switch (R1) {
-    case 64: return &launch_local_pj<64, S>;
-    case 128: return &launch_local_pj<128, S>;
+    case 16: return &launch_local_pj<16, 3>;
+    case 32: return &launch_local_pj<32, 3>;
+    case 64: return &launch_local_pj<64, 3>;
+    case 128: return &launch_local_pj<128, 3>;
+    case 256: return &launch_local_pj<256, 2>;
     default: return nullptr;
     }
 }

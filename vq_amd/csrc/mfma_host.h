@@ -28,7 +28,7 @@ LaunchFn direct_launcher(int R, int KP, int *samples_per_batch);
 LaunchFn long_launcher(int tiles);                                               // kernels_long.hip: k_long (rows above 256 values)
 LaunchFn local_long_launcher(int tiles);    // k_local_long<tiles>: LGMLVQ over rows above 256 values
 LaunchFn omega_long_launcher(int R2);                                            // kernels_long.hip: k_omega_long
-// kernels_local.hip: k_local_pj (LGMLVQ, projections on the bf16 matrix cores); R1 in {64, 128}
+// kernels_local.hip: k_local_pj (LGMLVQ, projections on the bf16 matrix cores); R1 in {16, 32, 64, 128, 256}
 LaunchFn local_pj_launcher(int R1, int *samples_per_batch);
 
 // batch counters of one launch (BlockQueue, mfma_device.h): QUEUE_GROUPS counters, 4 KiB apart
