@@ -321,7 +321,7 @@ int run_device(vqhip_ctx *c, const float *dX, uint64_t N, const uint32_t *dy, Ou
         }
         c->last_kernel = "mfma_omega_two_pass";
         c->last_ranking = engine_ranking(c->engine2);
-        c->last_projection = "f32";
+        c->last_projection = !c->proj_long && project_on_bf16(c->proj_omega) ? "bf16x6" : "f32";
         return scratch_release(c, s);
     }
 

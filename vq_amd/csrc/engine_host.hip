@@ -135,31 +135,6 @@ int variant_env()
 // bf16 pieces of the first tiles of a search image, in the layout search_tiles_bf reads (mfma_device.h BF_TILE_BYTES):
 // rows at the f32 tile's pitch; per reduction step q and lane half h the hi pieces of the lane's 8 values (16 bytes), then
 // their lo pieces.  Round to nearest even like v_cvt_pk_bf16_f32; lo = bf16(v - hi) with the difference exact in f32.
-uint16_t to_bf16(float v)                      // round to nearest even, like v_cvt_pk_bf16_f32
-{
-    uint32_t b;
-    std::memcpy(&b, &v, 4);
-    if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)((b >> 16) | 0x40u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (uint16_t)(b >> 16);
-}
-float from_bf16(uint16_t p)
-{
-    const uint32_t b = (uint32_t)p << 16;
-    float f;
-    std::memcpy(&f, &b, 4);
-    return f;
-}
-// v = p[0] + p[1] + p[2] (mfma_device.h split3: the remainders are exact in f32)
-void split3_host(float v, uint16_t (&p)[3])
-{
-    p[0] = to_bf16(v);
-    volatile float r = v - from_bf16(p[0]);
-    p[1] = to_bf16(r);
-    volatile float s = r - from_bf16(p[1]);
-    p[2] = to_bf16(s);
-}
-
 template <int R>
 std::vector<float> build_bf_tiles(const std::vector<float> &img, uint32_t nbf)
 {
@@ -511,42 +486,26 @@ template <int R1>
 bool bind_local_pj(EngineModel &m, std::vector<float> &img, const std::vector<float> &Oms, const std::vector<float> &negp,
                    const std::vector<uint32_t> &cls)
 {
-    using G3 = Geom3<R1>;
     if (m.R1 != (uint32_t)R1 || getenv("VQHIP_NO_BF") || getenv("VQHIP_NO_BF_PROJ")) return false;
     int spb = 0;
     const LaunchFn fn = local_pj_launcher(R1, &spb);
     if (!fn) return false;
-    const uint32_t tpp = (m.M + 31) / 32;
-    const size_t tiles = (size_t)m.K * tpp, ngroups = (tiles + G3::G - 1) / G3::G;
-    std::vector<unsigned char> bytes(ngroups * G3::STAGE_BYTES, 0);
-    for (size_t t = 0; t < ngroups * G3::G; ++t) {
-        unsigned char *tile = bytes.data() + t * G3::TILE_BYTES;
-        float *tail = reinterpret_cast<float *>(tile + G3::W_BYTES);
-        const size_t j = t / tpp;
-        for (int r = 0; r < 32; ++r) {
-            const uint32_t row = 32u * (uint32_t)(t % tpp) + r;
-            uint32_t c = 0xFFFFFFFFu;
-            if (j < m.K) {
-                if (row < m.M) {
-                    const float *src = &Oms[((size_t)j * m.M + row) * m.D];
-                    for (uint32_t d = 0; d < m.D; ++d) {
-                        // value d of the row: step d / 16, lane half (d / 4) & 1, element (d & 3) + 4 ((d / 8) & 1)
-                        uint16_t p[3];
-                        split3_host(src[d], p);
-                        const int q = d / 16, hh = (d / 4) & 1, e = (d & 3) + 4 * ((d / 8) & 1);
-                        for (int cc = 0; cc < 3; ++cc)
-                            std::memcpy(tile + G3::piece_off(r, q, hh, cc) + 2 * e, &p[cc], 2);
-                    }
-                    tail[r] = negp[j * m.M + row];
-                }
-                if (!cls.empty()) c = cls[j];
+    // every Omega_j padded to whole 32-row tiles, so a tile never straddles two prototypes (as bind_local)
+    const uint32_t tpp = (m.M + 31) / 32, rows_pp = tpp * 32;
+    std::vector<float> rows((size_t)m.K * rows_pp * m.D, 0.0f), init((size_t)m.K * rows_pp, 0.0f);
+    std::vector<uint32_t> rcls((size_t)m.K * rows_pp, 0xFFFFFFFFu);
+    for (uint32_t j = 0; j < m.K; ++j)
+        for (uint32_t r = 0; r < rows_pp; ++r) {
+            const size_t o = (size_t)j * rows_pp + r;
+            if (r < m.M) {
+                std::memcpy(&rows[o * m.D], &Oms[((size_t)j * m.M + r) * m.D], m.D * sizeof(float));
+                init[o] = negp[(size_t)j * m.M + r];
             }
-            std::memcpy(&tail[32 + r], &c, 4);
+            if (!cls.empty()) rcls[o] = cls[j];
         }
-    }
-    img.assign(bytes.size() / 4, 0.0f);
-    std::memcpy(img.data(), bytes.data(), bytes.size());
-    m.ngroups1 = (uint32_t)ngroups;
+    uint32_t ngroups = 0;
+    img = build_images3<R1>(rows.data(), rows.size() / m.D, m.D, m.D, init.data(), rcls.data(), ngroups);
+    m.ngroups1 = ngroups;
     m.tiles_per_proto = tpp;
     m.launch = fn;
     m.samples_per_batch = spb;

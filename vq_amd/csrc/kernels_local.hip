@@ -21,50 +21,6 @@
 
 namespace vq {
 
-// acc[s] = init column + tile . x[s]^T for one Geom3 tile in LDS (rows = the tile's 32 Omega_j rows, column = sample)
-template <int R, int S>
-__device__ __forceinline__ void tile_mma_pj(const char *tile, const u32x4 (&xp)[S][R / 16][3], f32x16 (&acc)[S], int row, int h)
-{
-    using G3 = Geom3<R>;
-    const float *tail = (const float *)(tile + G3::W_BYTES);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
-            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
-        }
-    }
-    const char *rowp = tile + G3::piece_off(row, 0, h, 0);
-    u32x4 an[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) an[c] = *(const u32x4 *)(rowp + 16 * c);
-    static_for<0, R / 16>([&](auto qq) {
-        constexpr int q = decltype(qq)::value;
-        u32x4 av[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) av[c] = an[c];
-        if constexpr (q + 1 < R / 16) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) an[c] = *(const u32x4 *)(rowp + 96 * (q + 1) + 16 * c);
-        }
-        // smallest class of products first; the S chains side by side
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[2], xp[s][q][0], acc[s]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[1], xp[s][q][1], acc[s]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[0], xp[s][q][2], acc[s]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[1], xp[s][q][0], acc[s]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[0], xp[s][q][1], acc[s]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[s] = mma_bf(av[0], xp[s][q][0], acc[s]);
-    });
-}
-
 template <int R1, int S, bool MATCHED>
 __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
 {

@@ -21,7 +21,7 @@ struct ProjectArgs {
     const float *X;           // N x D, rows 4-byte aligned
     uint64_t N;
     uint32_t D;               // <= R; values at or past D are cut inside the kernel
-    const float *img;         // ntiles tiles of Geom<R>
+    const float *img;         // ntiles tiles of Geom<R> (PJ: of Geom3<R>)
     uint32_t ntiles;
     float *Y;                 // N x ldy
     uint32_t ldy, col0, out_dim;   // this launch writes columns [col0, min(col0 + 32 ntiles, out_dim))
@@ -30,10 +30,14 @@ struct ProjectArgs {
 };
 
 // CUT: rows shorter than R (any length, 4-byte aligned): one register set, cut at D in place once it has landed.
-template <int R, bool CUT, int NW = 8>
+// PJ: the products on the bf16 matrix cores (mfma_device.h split3 / tile_mma_pj): A resident as Geom3 tiles (three bf16
+// pieces per value), a batch's rows split into pieces once, six piece products per product -- as exact as the f32 chain
+// (tools/bf16x6_probe.hip) at 2.7 times its matrix-pipe rate, which leaves these kernels to the memory pipe.
+template <int R, bool CUT, int NW = 8, bool PJ = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a)
 {
     using Gm = Geom<R>;
+    constexpr uint32_t TILE_BYTES = PJ ? Geom3<R>::TILE_BYTES : Gm::TILE_BYTES;
     // Register sets of 32 rows each.  R <= 128: two, worked alternately -- the loads that refill a set go
     // out right behind its last MFMA and have the other set's whole batch to land, with no copies between
     // sets.  R = 256: one set is all the register file holds at two waves per SIMD; the partner wave of
@@ -43,7 +47,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     {
-        const uint32_t bytes = a.ntiles * Gm::TILE_BYTES;
+        const uint32_t bytes = a.ntiles * TILE_BYTES;
         const char *src = (const char *)a.img;
         for (uint32_t p = wave; p * 1024u < bytes; p += NW) {
             const uint32_t off = p * 1024u + lane * 16u;
@@ -87,26 +91,38 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
 
     // all tiles of one batch: Y[b*32 + s][col0 + 32 t + 8 g + 4 h .. + 3] = accumulator group g of tile t
     const bool vec_store = (a.ldy & 3u) == 0u && ((uintptr_t)a.Y & 15u) == 0u;    // else 4-byte stores, column by column
-    auto project_batch = [&](f32x4 (&xs)[R / 8], uint64_t bb, bool claim) {
+    // (always_inline: called once per register set; as a real call the sets would live in scratch)
+    auto project_batch = [&](f32x4 (&xs)[R / 8], uint64_t bb, bool claim) __attribute__((always_inline)) {
         if constexpr (CUT) {
 #pragma unroll
             for (int j = 0; j < R / 8; ++j) xs[j] = mask_chunk(xs[j], (uint32_t)(2 * j + h), a.D);
         }
         const __amdgpu_buffer_rsrc_t ry =
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.Y + bb * 32 * a.ldy), 0, (int)records(bb, ybytes), 0x00020000);
+        u32x4 xp[1][PJ ? R / 16 : 1][3];                       // PJ: the batch's rows as pieces (the f32 rows are dead behind this)
+        if constexpr (PJ) {
+#pragma unroll
+            for (int q = 0; q < R / 16; ++q) split24(xs[2 * q], xs[2 * q + 1], xp[0][q]);
+        }
         for (uint32_t t = 0; t < a.ntiles; ++t) {
-            const float *rowp = img + (size_t)t * Gm::TILE_FLOATS + Gm::chunk_off(s_col, h);
             f32x16 acc;
+            if constexpr (PJ) {
+                f32x16 accs[1];
+                tile_mma_pj<R, 1>((const char *)img + (size_t)t * TILE_BYTES, xp, accs, s_col, h);   // (the tiles' init columns are zero)
+                acc = accs[0];
+            } else {
+                const float *rowp = img + (size_t)t * Gm::TILE_FLOATS + Gm::chunk_off(s_col, h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            f32x4 anext = *(const f32x4 *)rowp;
-            static_for<0, R / 8>([&](auto jj) {
-                constexpr int j = decltype(jj)::value;
-                const f32x4 acur = anext;
-                if constexpr (j + 1 < R / 8) anext = *(const f32x4 *)(rowp + 8 * (j + 1));
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                f32x4 anext = *(const f32x4 *)rowp;
+                static_for<0, R / 8>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value;
+                    const f32x4 acur = anext;
+                    if constexpr (j + 1 < R / 8) anext = *(const f32x4 *)(rowp + 8 * (j + 1));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[e], xs[j][e], acc, 0, 0, 0);
-            });
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[e], xs[j][e], acc, 0, 0, 0);
+                });
+            }
             // the claim for the block after next goes out once this block's rows have been waited for
             if (claim && t == 0) {
                 asm volatile("" ::: "memory");
@@ -145,6 +161,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_project(const ProjectArgs a
 // ------------------------------------------------------------------------------ host side
 struct ProjectModel {
     uint32_t rows = 0, D = 0, R = 0, ntiles = 0, tile_floats = 0, tiles_per_launch = 0;
+    bool pj = false;                                 // Geom3 tiles, products on the bf16 matrix cores
     float *img = nullptr;
     uint32_t *queue = nullptr;                       // QUEUE_SLOTS counters, as in EngineModel
     mutable uint32_t next_slot = 0;
@@ -167,13 +184,37 @@ hipError_t launch_project_t(const ProjectArgs &a, hipStream_t st)
 }
 
 template <int R>
+hipError_t launch_project_pj(const ProjectArgs &a, hipStream_t st)
+{
+    const uint64_t wgs = (a.nbatches + 7) / 8;
+    const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    if (a.D < (uint32_t)R)
+        hipLaunchKernelGGL((k_project<R, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_project<R, false, 8, true>), dim3(grid), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+
+template <int R>
 bool bind_project(ProjectModel &m, std::vector<float> &img, const std::vector<float> &A)
 {
     if (m.D > (uint32_t)R || (R > 32 && m.D <= (uint32_t)R / 2)) return false;       // narrowest instantiation that holds a row
     uint32_t ngroups = 0;
-    img = build_images<R>(A.data(), m.rows, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, ngroups);
     m.R = R;
     m.ntiles = (m.rows + 31) / 32;
+    if constexpr (R <= 128) {
+        if (!getenv("VQHIP_NO_BF") && !getenv("VQHIP_NO_BF_PROJ")) {
+            img = build_images3<R>(A.data(), m.rows, m.D, m.D, nullptr, nullptr, ngroups);
+            m.tile_floats = Geom3<R>::TILE_BYTES / 4;
+            m.tiles_per_launch = (uint32_t)(RES_BYTES / Geom3<R>::TILE_BYTES);
+            m.launch = &launch_project_pj<R>;
+            m.pj = true;
+            return true;
+        }
+    }
+    img = build_images<R>(A.data(), m.rows, m.D, m.D, 1.0f, nullptr, nullptr, 0.0f, ngroups);
     m.tile_floats = Geom<R>::TILE_FLOATS;
     m.tiles_per_launch = (uint32_t)(RES_BYTES / Geom<R>::TILE_BYTES);
     m.launch = &launch_project_t<R>;
@@ -199,6 +240,8 @@ ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t
     }
     return out;
 }
+
+bool project_on_bf16(const ProjectModel *m) { return m && m->pj; }
 
 void project_free(ProjectModel *m)
 {

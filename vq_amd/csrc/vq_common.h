@@ -82,6 +82,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
 struct ProjectModel;
 ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t D, hipError_t &herr);
 void project_free(ProjectModel *m);
+bool project_on_bf16(const ProjectModel *m);          // the products run as six bf16 piece products (Geom3 tiles)
 hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float *dY, uint32_t ldy, hipStream_t s);
 
 // project / project_omega for a global Omega of at most 128 rows over rows above 256 values (kernels_long.hip)
