@@ -352,7 +352,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             }
             auto fetch_next = [&]() { fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0); };
             constexpr bool AHEAD = BFIMG && SWAP && !MATCHED;   // the fetch goes out inside finish_keys_ahead instead
-            if constexpr (SWAP && !AHEAD) {            // the pieces are dead: the next batch's rows take their registers
+            // The labelled search re-measures up to four rows from L2 (two class groups): vmcnt completes in order, so with the
+            // samples requested first every one of those rows would queue behind an HBM round trip.  Its fetch goes out
+            // BEHIND the re-measurement instead (the rows of two groups in flight beside the samples do not fit the registers).
+            constexpr bool LATE = BFIMG && SWAP && MATCHED;
+            if constexpr (SWAP && !AHEAD && !LATE) {   // the pieces are dead: the next batch's rows take their registers
                 asm volatile("" ::: "memory");
                 fetch_next();
             }
@@ -361,9 +365,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             Best1 wp, wn;
             if constexpr (AHEAD)       // the next batch's rows go out behind the request for the candidate's row
                 finish_keys_ahead<R>(xf, a.plain, a.ldp, a.K, h, unsafe, margin, ku, wp, [&]() { fetch_next(); });
-            else if constexpr (BFIMG)
+            else if constexpr (BFIMG) {
                 finish_keys_g<R, MATCHED>(xf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
-            else finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+                if constexpr (LATE) {
+                    asm volatile("" ::: "memory");
+                    fetch_next();
+                }
+            } else finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
             {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
                 const int rec = (int)records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;
