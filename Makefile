@@ -19,7 +19,7 @@ ROWS_BENCH  := tools/host_rows_bench
 
 MODELS_TEST_STATIC := tests/cpp/test_models_static
 
-all: $(LIB) $(LIBA) oracle $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream tools/bf16x3_probe tools/bf16x6_probe tools/issue_probe asan
+all: $(LIB) $(LIBA) oracle $(MODELS_TEST) $(MODELS_TEST_STATIC) $(ROWS_BENCH) tools/hbm_stream tools/bf16x3_probe tools/bf16x6_probe tools/issue_probe tools/local_probe asan
 
 $(LIBA): $(OBJS)
 	rm -f $@ && ar rcs $@ $(OBJS)
@@ -36,6 +36,8 @@ tools/bf16x3_probe: tools/bf16x3_probe.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
 tools/bf16x6_probe: tools/bf16x6_probe.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
+tools/local_probe: tools/local_probe.hip $(CSRC)/mfma_device.h
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -Iinclude -I$(CSRC) $< -o $@
 tools/issue_probe: tools/issue_probe.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
 
