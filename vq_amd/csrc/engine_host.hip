@@ -667,6 +667,21 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         return nullptr;
     }
 
+    // the streamed engine with the bf16 ranking reads its search tiles as READY pieces (tile_mma_ready): same tiles, same
+    // tails, the f32 values replaced by their pieces -- nothing else reads them (exact distances come from `plain`)
+    if (m.bf && m.lds_used == 0 && (m.mode == MODE_EUCLID || m.mode == MODE_OMEGA) &&
+        (std::strcmp(m.name, "mfma_euclid") == 0 || std::strcmp(m.name, "mfma_omega") == 0)) {
+        std::vector<float> &simg = m.mode == MODE_EUCLID ? img1 : img2;
+        const uint32_t R = m.mode == MODE_EUCLID ? m.R1 : m.R2;
+        switch (R) {
+        case 16: pieces_image<16>(simg, (uint32_t)(simg.size() / Geom<16>::TILE_FLOATS)); break;
+        case 32: pieces_image<32>(simg, (uint32_t)(simg.size() / Geom<32>::TILE_FLOATS)); break;
+        case 64: pieces_image<64>(simg, (uint32_t)(simg.size() / Geom<64>::TILE_FLOATS)); break;
+        case 128: pieces_image<128>(simg, (uint32_t)(simg.size() / Geom<128>::TILE_FLOATS)); break;
+        default: why = "bf16 ranking on a search width without a pieces image"; return nullptr;
+        }
+    }
+
     std::vector<float> imgbf;
     if (m.bf && m.lds_used != 0) {
         std::vector<float> &simg = m.search_img == 1 ? img1 : img2;

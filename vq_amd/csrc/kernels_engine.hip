@@ -30,7 +30,8 @@ namespace vq {
 // projected, so the next batch's rows are fetched into the same registers while the search runs
 // (every workgroup of the chip loading, then computing, in lockstep is an HBM burst followed by HBM
 // silence).  The search stages screen with packed keys (4 VALU per score, see k_resident_pipe).
-// BF: the search stage's products on the bf16 matrix cores (tile_mma_bf, mfma_device.h); projections stay f32.
+// BF: the search stage's products on the bf16 matrix cores (tile_mma_ready, mfma_device.h): the search image then holds
+// the prototypes' bf16 pieces (nothing else reads its values: the exact re-measurement and scan go to a.plain); projections stay f32.
 template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, bool BF = false>
 __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
 {
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     for (int tt = 0; tt < G2::G; ++tt) {
                         const float *tile = stage + tt * G2::TILE_FLOATS;
                         f32x16 acc[S];
-                        if constexpr (BF) tile_mma_bf<RS, S>(tile, bh, bl, acc, s_col, h);
+                        if constexpr (BF) tile_mma_ready<RS, S>(tile, bh, bl, acc, s_col, h);   // (the stage holds pieces: engine_build)
                         else tile_mma<RS, S>(tile, yf, acc, s_col, h);
                         const uint32_t tile_id = qs * G2::G + tt;
                         const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32 + 4 * h;

@@ -895,6 +895,38 @@ __device__ __forceinline__ void tile_mma_bf(const float *tile, const u32x4 (&bh)
     }
 }
 
+// tile_mma_bf over a tile of READY pieces (host: pieces_image / build_bf_tiles: per row, step q and lane half h 16 bytes
+// of hi pieces and 16 of lo at byte 64 q + 32 h of the f32 row's pitch; the tail is the f32 tile's): nothing is split,
+// every pair of LDS reads serves the S sample tiles of the wave.  The streamed engine's search stage.
+template <int R, int S>
+__device__ __forceinline__ void tile_mma_ready(const float *tile, const u32x4 (&bh)[S][R / 16], const u32x4 (&bl)[S][R / 16], f32x16 (&acc)[S],
+                                               int row, int h)
+{
+    using Gm = Geom<R>;
+    const float *tail = tile + Gm::W_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            acc[s][4 * g + 0] = ci[0]; acc[s][4 * g + 1] = ci[1];
+            acc[s][4 * g + 2] = ci[2]; acc[s][4 * g + 3] = ci[3];
+        }
+    }
+    const char *rowp = (const char *)tile + row * (Gm::ROW_FLOATS * 4) + 32 * h;
+#pragma unroll
+    for (int q = 0; q < R / 16; ++q) {
+        const bf16x8 vah = __builtin_bit_cast(bf16x8, *(const u32x4 *)(rowp + 64 * q));
+        const bf16x8 val = __builtin_bit_cast(bf16x8, *(const u32x4 *)(rowp + 64 * q + 16));
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, __builtin_bit_cast(bf16x8, bh[s][q]), acc[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, __builtin_bit_cast(bf16x8, bl[s][q]), acc[s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, __builtin_bit_cast(bf16x8, bh[s][q]), acc[s], 0, 0, 0);
+    }
+}
+
 // Bytes of one tile of bf16 pieces (host: build_bf_tiles): the rows of the f32 tile at the same pitch, each row holding,
 // per reduction step q and lane half h, the 8 hi pieces and then the 8 lo pieces of that lane's values (16 + 16 bytes).
 template <int R>
