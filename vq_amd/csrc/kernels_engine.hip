@@ -104,6 +104,14 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         }
     };
 
+#ifdef VQ_ENGINE_DIAG      // phase stamps and the in-kernel clock (engine_assign prints them: VQHIP_VARIANT=35 VQHIP_DUMP=1 [VQHIP_NW4=1 for WPS = 1])
+    const unsigned long long t_begin = stamp(), r_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = t_begin;
+    auto lap = [&](int slot) { const unsigned long long t = stamp(); tm[slot] += t - tprev_; tprev_ = t; };
+#define VQ_LAP(i) lap(i)
+#else
+#define VQ_LAP(i)
+#endif
     int cur = 0;
     uint64_t b = blockIdx.x;
     if (b < a.nbatches) {
@@ -164,7 +172,9 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         uint32_t q = 0;
         auto step = [&](auto &&compute) {
             const bool wrap = q + 1 == ngroups;
+            VQ_LAP(3);                     // 3: everything outside the three phases of a stage
             if (!(wrap && bnext >= a.nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);   // nothing to stage after the last batch
+            VQ_LAP(0);                     // 0: issue of the next stage's DMA
             if (MODE == MODE_OMEGA && q == (uint32_t)NG1) {
                 // x is dead: the next batch's rows are fetched now and arrive while the search runs.  vmcnt
                 // counts in issue order, so they go out AFTER this step's DMA, and this step's barrier waits
@@ -175,7 +185,9 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(S * (R1 / 8) + (MATCHED ? S : 0)) : "memory");
             } else {
                 compute((const float *)(smem + cur * BUF_BYTES));
+                VQ_LAP(1);                 // 1: the stage's tiles
                 __syncthreads();               // next stage landed (vmcnt(0)) and everyone is done reading this one
+                VQ_LAP(2);                 // 2: the barrier (and the wait for the DMA in it)
             }
             cur ^= 1;
             ++q;
@@ -353,6 +365,16 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         if (MODE != MODE_OMEGA) load_samples(bnext);
         b = bnext;
     }
+#ifdef VQ_ENGINE_DIAG
+    if (a.dbg && lane == 0) {
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        for (int i = 0; i < 4; ++i) d[i] = tm[i];
+        d[4] = stamp() - t_begin;
+        d[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
+        d[6] = r_begin;
+        d[7] = r_begin + d[5];
+    }
+#endif
 }
 
 namespace {
