@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         // ---- search in the projected space (k_resident_pipe's tile loop)
         Keys2 ku;
         KeysM km;
-        if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above stays f32
+        if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above: f32, or bf16x6 with PJ
             u32x4 bh[R / 16], bl[R / 16];
             split_fragment<R>(yf, bh, bl);
             if constexpr (BFIMG)
