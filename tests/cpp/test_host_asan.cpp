@@ -24,7 +24,7 @@ LaunchFn direct_launcher(int R, int KP, int *spb) { *spb = 64; return pow2_in(R,
 LaunchFn long_launcher(int tiles) { return tiles == 1 || tiles == 2 || tiles == 4 || tiles == 8 ? &no_device : nullptr; }
 LaunchFn local_long_launcher(int tiles) { return tiles == 1 || tiles == 2 || tiles == 4 ? &no_device : nullptr; }
 LaunchFn omega_long_launcher(int R2) { return pow2_in(R2, 32, 128) ? &no_device : nullptr; }
-LaunchFn local_pj_launcher(int R1, int *spb) { *spb = R1 == 256 ? 256 : 384; return pow2_in(R1, 16, 256) ? &no_device : nullptr; }
+LaunchFn local_pj_launcher(int R1, int *spb) { *spb = R1 == 256 ? 256 : R1 == 128 ? 512 : 384; return pow2_in(R1, 16, 256) ? &no_device : nullptr; }
 }  // namespace vq
 
 namespace {
@@ -150,7 +150,7 @@ int main()
                     if (l.pj && D > 64 && D <= 128) {       // Geom3 tiles: the three pieces of every weight add up to it exactly, tails in place
                         using G3 = Geom3<128>;
                         const uint32_t tpp = (M + 31) / 32;
-                        CHECK(c.size() * 4 == (size_t)l.ngroups1 * G3::STAGE_BYTES && l.ngroups1 == K * tpp && l.samples_per_batch == 384);
+                        CHECK(c.size() * 4 == (size_t)l.ngroups1 * G3::STAGE_BYTES && l.ngroups1 == K * tpp && l.samples_per_batch == 512);
                         const unsigned char *bytes = reinterpret_cast<const unsigned char *>(c.data());
                         for (uint32_t j = 0; j < K; ++j)
                             for (uint32_t r = 0; r < M; r += 7)

@@ -10,10 +10,11 @@
 // Same skeleton as k_engine: a workgroup of 4 waves walks the stream of Omega_j tiles through a double-buffered LDS
 // stage filled by LDS-DMA, one barrier per stage; batches are claimed from a counter.  What differs:
 //   * the tiles are Geom3 tiles (engine.h): 6 bytes per weight, read as three ds_read_b128 per step;
-//   * a wave holds S = 3 tiles of 32 samples as PIECES (288 registers) -- one workgroup per CU, one wave per SIMD, the
-//     whole register file; the three samples' chains are independent, which is what keeps the matrix pipe fed by a
-//     single wave -- so a staged tile (25 KiB for 128 values) serves 384 samples, and the stream of all Omega_j (6.5 MB
-//     for config 5, more than an XCD's L2 holds) stays near 2 TB/s chip-wide;
+//   * a wave holds S tiles of 32 samples as PIECES (96 registers per tile at 128 values), one workgroup per CU: two waves
+//     per SIMD with S = 2 at 128 values, one wave with S = 3 (S = 2 at 256 values) and the whole register file otherwise;
+//     the tiles' chains are independent, which is what keeps the matrix pipe fed -- so a staged tile (25 KiB for 128
+//     values) serves 512 samples, and the stream of all Omega_j (6.5 MB for config 5, more than an XCD's L2 holds) stays
+//     below 2 TB/s chip-wide;
 //   * the sample rows are dead once split, and are fetched again for the next batch behind the last tile.
 #include <cstdlib>
 
@@ -21,22 +22,37 @@
 
 namespace vq {
 
-template <int R1, int S, bool MATCHED>
-__global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
+// stage_group (mfma_device.h) for NW waves
+template <int BYTES, int NW>
+__device__ __forceinline__ void stage_group_nw(char *lds_dst, const char *gsrc, int wave, int lane)
+{
+    constexpr int PIECES = (BYTES + 1023) / 1024;
+#pragma unroll
+    for (int i = 0; i < (PIECES + NW - 1) / NW; ++i) {
+        const int p = i * NW + wave;
+        const int off = p * 1024 + lane * 16;
+        if (p < PIECES && off < BYTES)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + off),
+                                             (__attribute__((address_space(3))) void *)(lds_dst + p * 1024), 16, 0, 0);
+    }
+}
+
+template <int R1, int S, bool MATCHED, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 1) k_local_pj(const EngineArgs a)
 {
     using G3 = Geom3<R1>;
     constexpr int NQ = R1 / 16;
     __shared__ __attribute__((aligned(16))) char smem[2 * G3::STAGE_BYTES];
     __shared__ uint32_t claimed;                                     // the batch after this one
     __shared__ __attribute__((aligned(16))) float mu_lds[R1];
-    stage_centre<R1>(mu_lds, a.mu, threadIdx.x, 256);                // published by the first barrier below
+    stage_centre<R1>(mu_lds, a.mu, threadIdx.x, NW * 64);                // published by the first barrier below
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s_col = lane & 31, h = lane >> 5;
     const uint32_t ngroups = a.ngroups1;
 
     auto issue = [&](uint32_t q, int buf) {                          // stage q of the cyclic stream of Omega_j tiles
-        stage_group<G3::STAGE_BYTES>(smem + buf * G3::STAGE_BYTES, (const char *)a.img1 + (size_t)q * G3::STAGE_BYTES, wave, lane);
+        stage_group_nw<G3::STAGE_BYTES, NW>(smem + buf * G3::STAGE_BYTES, (const char *)a.img1 + (size_t)q * G3::STAGE_BYTES, wave, lane);
     };
 
     // this wave's S tiles of 32 samples of batch bb, straight from HBM through a range-checked buffer descriptor
@@ -49,7 +65,7 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
     auto load_samples = [&](uint64_t bb) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const uint64_t first = ((bb * 4 + wave_u) * S + s) * 32;
+            const uint64_t first = ((bb * NW + wave_u) * S + s) * 32;
             uint32_t rec = 0u, rec_y = 0u;
             if (bb < a.nbatches && first < a.N) {
                 const uint64_t left = a.N - first;
@@ -109,7 +125,7 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
             if (a.mu != nullptr) centre_fragment<R1 / 8, 2>(xf[s], mu_lds, h);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) split24(xf[s][2 * q], xf[s][2 * q + 1], xp[s][q]);
-            sample[s] = ((b * 4 + wave) * S + s) * 32 + s_col;
+            sample[s] = ((b * NW + wave) * S + s) * 32 + s_col;
             lab[s] = label[s];
         }
 
@@ -176,7 +192,7 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
     }
 #ifdef VQ_LOCAL_DIAG
     if (a.dbg && lane == 0) {
-        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
         for (int i = 0; i < 4; ++i) d[i] = tm[i];
         d[4] = stamp() - t_begin;
         d[5] = __builtin_amdgcn_s_memrealtime() - r_begin;
@@ -187,33 +203,37 @@ __global__ void __launch_bounds__(256, 1) k_local_pj(const EngineArgs a)
 }
 
 namespace {
-template <int R1, int S>
+template <int R1, int S, int NW = 4>
 hipError_t launch_local_pj(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const unsigned grid = (unsigned)(a.nbatches < 256 ? a.nbatches : 256);      // one workgroup per CU
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if (matched)
-        hipLaunchKernelGGL((k_local_pj<R1, S, true>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_local_pj<R1, S, true, NW>), dim3(grid), dim3(NW * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((k_local_pj<R1, S, false>), dim3(grid), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_local_pj<R1, S, false, NW>), dim3(grid), dim3(NW * 64), 0, st, a);
     return hipGetLastError();
 }
 }  // namespace
 
 LaunchFn local_pj_launcher(int R1, int *samples_per_batch)
 {
-    // S sample tiles per wave as pieces: 12 S registers per 16 values of a row
-    const int S = R1 == 256 ? 2 : 3;
-    *samples_per_batch = 4 * S * 32;                                  // 4 waves x S tiles x 32 samples
+    // S sample tiles per wave as pieces (12 S registers per 16 values of a row), NW waves per workgroup, one workgroup per CU.
+    // 128 values: two waves per SIMD with two tiles each measured 6.8 % faster than one wave with three (config 5, one box:
+    // 31.2 against 33.2 ms per 4M rows; 8 x 1: 34.4, 12 x 1: 32.0), the other lengths keep four waves.
+    int S = 3, NW = 4;
+    LaunchFn fn = nullptr;
     switch (R1) {
-    case 16: return &launch_local_pj<16, 3>;
-    case 32: return &launch_local_pj<32, 3>;
-    case 64: return &launch_local_pj<64, 3>;
-    case 128: return &launch_local_pj<128, 3>;
-    case 256: return &launch_local_pj<256, 2>;
+    case 16: fn = &launch_local_pj<16, 3>; break;
+    case 32: fn = &launch_local_pj<32, 3>; break;
+    case 64: fn = &launch_local_pj<64, 3>; break;
+    case 128: fn = &launch_local_pj<128, 2, 8>; S = 2; NW = 8; break;
+    case 256: fn = &launch_local_pj<256, 2>; S = 2; break;
     default: return nullptr;
     }
+    *samples_per_batch = NW * S * 32;                                 // NW waves x S tiles x 32 samples
+    return fn;
 }
 
 }  // namespace vq
