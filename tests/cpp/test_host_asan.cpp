@@ -24,7 +24,7 @@ LaunchFn direct_launcher(int R, int KP, int *spb) { *spb = 64; return pow2_in(R,
 LaunchFn long_launcher(int tiles) { return tiles == 1 || tiles == 2 || tiles == 4 || tiles == 8 ? &no_device : nullptr; }
 LaunchFn local_long_launcher(int tiles) { return tiles == 1 || tiles == 2 || tiles == 4 ? &no_device : nullptr; }
 LaunchFn omega_long_launcher(int R2) { return pow2_in(R2, 32, 128) ? &no_device : nullptr; }
-LaunchFn local_pj_launcher(int R1, int *spb) { *spb = R1 == 256 ? 256 : R1 == 128 ? 512 : 384; return pow2_in(R1, 16, 256) ? &no_device : nullptr; }
+LaunchFn local_pj_launcher(int R1, int *spb) { *spb = R1 == 256 ? 256 : R1 >= 64 ? 512 : 384; return pow2_in(R1, 16, 256) ? &no_device : nullptr; }
 }  // namespace vq
 
 namespace {

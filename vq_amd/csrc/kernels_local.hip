@@ -11,7 +11,7 @@
 // stage filled by LDS-DMA, one barrier per stage; batches are claimed from a counter.  What differs:
 //   * the tiles are Geom3 tiles (engine.h): 6 bytes per weight, read as three ds_read_b128 per step;
 //   * a wave holds S tiles of 32 samples as PIECES (96 registers per tile at 128 values), one workgroup per CU: two waves
-//     per SIMD with S = 2 at 128 values, one wave with S = 3 (S = 2 at 256 values) and the whole register file otherwise;
+//     per SIMD from 64 values on (S = 2; S = 1 at 256 values), one wave with S = 3 and the whole register file below;
 //     the tiles' chains are independent, which is what keeps the matrix pipe fed -- so a staged tile (25 KiB for 128
 //     values) serves 512 samples, and the stream of all Omega_j (6.5 MB for config 5, more than an XCD's L2 holds) stays
 //     below 2 TB/s chip-wide;
@@ -221,15 +221,16 @@ LaunchFn local_pj_launcher(int R1, int *samples_per_batch)
 {
     // S sample tiles per wave as pieces (12 S registers per 16 values of a row), NW waves per workgroup, one workgroup per CU.
     // 128 values: two waves per SIMD with two tiles each measured 6.8 % faster than one wave with three (config 5, one box:
-    // 31.2 against 33.2 ms per 4M rows; 8 x 1: 34.4, 12 x 1: 32.0), the other lengths keep four waves.
+    // 31.2 against 33.2 ms per 4M rows; 8 x 1: 34.4, 12 x 1: 32.0); 64 values the same way +4 %, 256 values as 8 x 1
+    // against 4 x 2 +7.5 % (D = 200: +14 %); rows of up to 32 values keep four waves.
     int S = 3, NW = 4;
     LaunchFn fn = nullptr;
     switch (R1) {
     case 16: fn = &launch_local_pj<16, 3>; break;
     case 32: fn = &launch_local_pj<32, 3>; break;
-    case 64: fn = &launch_local_pj<64, 3>; break;
+    case 64: fn = &launch_local_pj<64, 2, 8>; S = 2; NW = 8; break;
     case 128: fn = &launch_local_pj<128, 2, 8>; S = 2; NW = 8; break;
-    case 256: fn = &launch_local_pj<256, 2>; S = 2; break;
+    case 256: fn = &launch_local_pj<256, 1, 8>; S = 1; NW = 8; break;
     default: return nullptr;
     }
     *samples_per_batch = NW * S * 32;                                 // NW waves x S tiles x 32 samples
