@@ -147,11 +147,23 @@ def matrix_work(cfg, ranking, projection="f32"):
     return f32_fl, bf_fl
 
 
+# What the SQ counters of profiles/ say binds a launch when it is not the roofline it is priced against:
+# the bf16-ranked kernels keep the matrix pipe about half busy -- vector issue (screening, epilogue) and the L2 / HBM
+# round trips of the batch epilogue fill the rest; the f32 kernels sit on the matrix pipe; few prototypes stream.
+def limiter_of(cfg, ranking, projection):
+    if cfg.name in HBM_BOUND:
+        return "hbm stream"
+    if ranking == "bf16x3" or projection == "bf16x6":
+        return "valu-issue + epilogue latency"
+    return "mfma"
+
+
 def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=None, ranking="f32", projection="f32"):
     """achieved = ALGORITHMIC flops (or bytes) per launch / launch time.  MFMA peak = the same algorithmic flops over the
     least time the matrix cores need for the instructions this kernel issues for them: f32 products at 157.3 TFLOP/s and,
     where the candidates are ranked on the bf16 cores, three bf16 piece products per algorithmic product at 2 516.6
-    (so 838.9 algorithmic TFLOP/s for a pure search).  The f32-only peak is kept beside it for comparison."""
+    (so 838.9 algorithmic TFLOP/s for a pure search), six per projection product.  `bound` names the roofline the
+    fraction is priced against (hbm | mfma), `limiter` what the counters say binds the launch."""
     fl, by = flops_per_sample(cfg), bytes_per_sample(cfg)
     secs = launch_ms * 1e-3
     tflops = rows * fl / secs / 1e12
@@ -159,22 +171,29 @@ def roofline_block(cfg, kernel, rows, launch_ms, traffic=None, traffic_source=No
     f32_fl, bf_fl = matrix_work(cfg, ranking, projection)
     t_min = f32_fl / (PEAK_F32_MFMA_TFLOPS * 1e12) + bf_fl / (PEAK_BF16_MFMA_TFLOPS * 1e12)       # per sample
     mfma_peak = fl / t_min / 1e12
-    blk = {"kernel": KERNEL_FN.get(kernel, "k_engine"), "ranking": ranking, "projection": projection, "launch_ms": launch_ms, "samples_per_launch": rows,
-           "flops_per_sample": fl, "bytes_per_sample": by, "traffic": traffic, "traffic_source": traffic_source,
-           "tflops": tflops, "mfma_frac_of_157.3": tflops / PEAK_F32_MFMA_TFLOPS,
-           "f32_mfma_flops_per_sample": f32_fl, "bf16_mfma_flops_per_sample": bf_fl,
-           "f32_mfma_busy_frac": rows * f32_fl / (PEAK_F32_MFMA_TFLOPS * 1e12) / secs,
-           "hbm_GBps_algorithmic": gbs, "hbm_frac_of_8TBps": gbs / PEAK_HBM_GBS}
+    blk = {}
     if cfg.name in HBM_BOUND:
         blk.update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
     else:
         blk.update({"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tflops / mfma_peak})
-        if ranking == "bf16x3" or projection == "bf16x6":
-            blk["peak_note"] = ("algorithmic flops over the matrix cores' least time for this instruction mix: f32 MFMA at 157.3 TFLOP/s, "
-                                "3 bf16 piece products per search product and 6 per projection product (where vqhip_last_projection says "
-                                "bf16x6) at 2516.6; the ranking changes no result (exact f32 re-measurement + in-kernel guard), the "
-                                "bf16x6 projection is as exact as the f32 chain (tools/bf16x6_probe.hip)")
+    blk.update({"traffic": traffic, "traffic_over_algorithmic": traffic / (rows * by) if traffic else None,
+                "traffic_source": traffic_source, "limiter": limiter_of(cfg, ranking, projection),
+                "kernel": KERNEL_FN.get(kernel, "k_engine"), "ranking": ranking, "projection": projection,
+                "launch_ms": launch_ms, "samples_per_launch": rows, "flops_per_sample": fl, "bytes_per_sample": by,
+                "tflops": tflops, "frac_of_f32_mfma_157.3": tflops / PEAK_F32_MFMA_TFLOPS,
+                "hbm_GBps": gbs, "hbm_frac_of_8TBps": gbs / PEAK_HBM_GBS})
     return blk
+
+
+def sig4(v):
+    """Floats to 4 significant digits, recursively: the JSON line has to survive the driver's tail."""
+    if isinstance(v, float):
+        return float(f"{v:.4g}")
+    if isinstance(v, dict):
+        return {k: sig4(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [sig4(x) for x in v]
+    return v
 
 
 # ------------------------------------------------------------------ HBM traffic from the PMC counters, live
@@ -213,7 +232,7 @@ def measure_traffic(workload, rows, kernel_fn):
             vals[counter] = sum(got) / len(got)
         finally:
             shutil.rmtree(out, ignore_errors=True)
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "live: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, KiB, this run"
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "live pmc: 2*FETCH_SIZE+WRITE_SIZE KiB"
 
 
 def stored_traffic(workload):
@@ -221,7 +240,7 @@ def stored_traffic(workload):
     try:
         e = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(workload)
         if e:
-            return e["hbm_bytes_per_launch"], "stored: profiles/" + e.get("from", "pmc_latest.json")
+            return e["hbm_bytes_per_launch"], "profiles/" + e.get("from", "pmc_latest.json")
     except Exception:
         pass
     return None, None
@@ -259,17 +278,15 @@ def cpu_baselines(cfg, model, first_row, faithful_rows, gpu_idx, budget_s=4.0):
     rows, dt, idx = run(faithful_rows if faithful_rows > 0 else budget_s * rate1 / macs(False), False, 1)
     same = bool((idx.view(np.int32) == gpu_idx[:rows]).all()) if gpu_idx is not None else None
     out.update({"value": rows / dt, "unit": "samples/s", "cores": 1, "kind": "port",
-                "sample": f"first {rows} rows of the same shard, f64 oracle, faithful mode (Lambda rebuilt per pair where "
-                          f"Omega is used, src/helpers.rs:38), {dt:.1f} s", "indices_equal_gpu": same})
+                "sample": f"first {rows} rows of the shard, f64 C oracle as the reference computes (Lambda per pair), {dt:.1f} s",
+                "indices_equal_gpu": same})
     if cfg.omega != "none":
         rows, dt, _ = run(budget_s * rate1 / macs(True), True, 1)
-        out["hoisted_1core"] = {"value": rows / dt, "unit": "samples/s", "cores": 1,
-                                "sample": f"{rows} rows, Lambda built once per model, {dt:.1f} s"}
+        out["hoisted_1core"] = rows / dt                 # Lambda built once per model, 1 core
     else:
-        out["hoisted_1core"] = {"value": out["value"], "unit": "samples/s", "cores": 1, "sample": "no Omega: same as the faithful leg"}
+        out["hoisted_1core"] = out["value"]              # no Omega: the faithful leg
     rows, dt, _ = run(budget_s * rate1 * cores * 0.7 / macs(True), True, cores)
-    out["all_cores"] = {"value": rows / dt, "unit": "samples/s", "cores": cores,
-                        "sample": f"{rows} rows, hoisted Lambda, {cores} threads over samples (the reference itself is single-threaded), {dt:.1f} s"}
+    out["all_cores"] = {"value": rows / dt, "cores": cores}     # hoisted Lambda, threads over samples
     return out
 
 
@@ -286,7 +303,7 @@ def run_rank(args):
     import torch
     import torch.distributed as dist
 
-    from vq_amd import synth
+    from vq_amd import OPT_PROJECTION, OPT_RANKING, VALUE_DEFAULT, VALUE_F32, synth
     from vq_amd.dist import gather_chunk, make_sharding
 
     rank = int(os.environ.get("RANK", "0"))
@@ -459,18 +476,17 @@ def run_rank(args):
         del X, idx_buf, dst_buf
         torch.cuda.empty_cache()
         line["extra"] = {}
-        # c2_f32 / c3_f32 / c5_f32: the same workloads with everything on the f32 matrix cores (VQHIP_NO_BF, read when the
-        # model's images are built): the kernels the f32-MFMA fractions of DESIGN.md section 5 are quoted on
+        # c2_f32 / c3_f32 / c5_f32: the same workloads with everything on the f32 matrix cores (vqhip_set_option): the
+        # kernels the f32-MFMA fractions of DESIGN.md section 5 are quoted on
         for name, xrows in (("c3", 10_000_000), ("c4", 10_000_000), ("c5", 4_000_000), ("c2k32", 10_000_000), ("c2k8", 10_000_000),
                             ("c2_f32", 10_000_000), ("c3_f32", 10_000_000), ("c5_f32", 4_000_000)):
             f32_only = name.endswith("_f32")
             xc = synth.CONFIGS[name[:-4] if f32_only else name]
             xm = synth.make_model(xc)
-            if f32_only:
-                os.environ["VQHIP_NO_BF"] = "1"
+            for opt in (OPT_RANKING, OPT_PROJECTION):
+                ctx.set_option(opt, VALUE_F32 if f32_only else VALUE_DEFAULT)
             synth.load_model(ctx, xm)
             ctx.prepare()
-            os.environ.pop("VQHIP_NO_BF", None)
             Xx = synth.samples_device(ctx, xm, 0, xrows)
             xi = torch.empty(xrows, dtype=torch.int32, device=dev)
             xd = torch.empty(xrows, dtype=torch.float32, device=dev)
@@ -491,20 +507,31 @@ def run_rank(args):
             ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
             traffic, source = stored_traffic(name) if not f32_only else (None, None)
             if traffic is not None and xrows != 10_000_000:     # every byte of these kernels' traffic is per batch of rows
-                traffic, source = traffic * xrows / 10_000_000, source + f" (profiled at 10000000 rows, scaled to {xrows})"
-            entry = {"workload": f"{xc.model} predict, synthetic {xrows}x{xc.D} f32, {xc.K} prototypes"
-                                 + (f", Omega {xc.M}x{xc.D} ({xc.omega})" if xc.omega != "none" else ""),
-                     "value": xrows * n_launch / wall, "unit": "samples/s", "launches": n_launch, "ms_per_step": wall / n_launch * 1e3,
-                     "kernel": ctx.last_kernel, "ranking": ctx.last_ranking, "projection": ctx.last_projection,
-                     "roofline": roofline_block(xc, ctx.last_kernel, xrows, ms, traffic, source, ctx.last_ranking, ctx.last_projection)}
+                traffic, source = traffic * xrows / 10_000_000, source + f" (10M-row profile scaled to {xrows})"
+            rb = roofline_block(xc, ctx.last_kernel, xrows, ms, traffic, source, ctx.last_ranking, ctx.last_projection)
+            entry = {"shape": f"{xc.model} {xrows}x{xc.D} K={xc.K}" + (f" Om={xc.M}x{xc.D} {xc.omega}" if xc.omega != "none" else ""),
+                     "value": xrows * n_launch / wall, "ms": wall / n_launch * 1e3, "launch_ms": ms, "kernel": ctx.last_kernel,
+                     "rank": ctx.last_ranking, "proj": ctx.last_projection}
+            entry.update({k: rb[k] for k in ("bound", "achieved", "peak", "unit", "frac", "limiter", "traffic_over_algorithmic",
+                                             "frac_of_f32_mfma_157.3", "hbm_frac_of_8TBps")})
             if args.cpu_rows != 0 and not f32_only:
-                entry["cpu_baseline"] = cpu_baselines(xc, xm, 0, 0, xi.cpu().numpy(), budget_s=2.5)
+                cb = cpu_baselines(xc, xm, 0, 0, xi.cpu().numpy(), budget_s=2.5)
+                entry["cpu_1core"] = cb["value"]
+                entry["cpu_all_cores"] = cb["all_cores"]["value"]
+                entry["cpu_idx_equal"] = cb["indices_equal_gpu"]
             line["extra"][name] = entry
             del Xx, xi, xd
             torch.cuda.empty_cache()
     if rank == 0:
+        if "extra" in line:
+            line["notes"] = ("extra: same timing, 20 launches (c5: 10, 4M rows); value = samples/s; peak of a bf16-ranked workload = algorithmic "
+                             "flops over the matrix cores' least time for its instruction mix (3 bf16 products per search product, 6 per "
+                             "projection product, f32 at 157.3); cpu_* = f64 C oracle on bounded samples (DESIGN.md 5)")
+            # last key: the driver keeps the tail of the line
+            line["extra_summary"] = {k: [e["value"], e["frac"], e["bound"]] for k, e in line["extra"].items()}
+            line["extra_summary"][line["config"]["name"]] = [line["value"], line["roofline"]["frac"], line["roofline"]["bound"]]
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os.write(json_fd, (json.dumps(sig4(line)) + "\n").encode())
     if gather:
         dist.destroy_process_group()
     if ctx is not None:

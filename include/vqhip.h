@@ -87,6 +87,19 @@ int vqhip_set_local_omegas(vqhip_ctx *ctx, const float *Oms, uint32_t K, uint32_
 
 int vqhip_set_kernel_policy(vqhip_ctx *ctx, int policy /* vqhip_kernel_policy */);
 
+/* Which matrix cores the MFMA kernels use.  No counterpart in the reference (f64 scalar code); results do not depend on
+ * VQHIP_OPT_RANKING at all (vqhip_last_ranking below) and on VQHIP_OPT_PROJECTION only to rounding, both settings inside
+ * the 1e-5 bar (vqhip_last_projection).  Setting an option invalidates the device images like any vqhip_set_*; the
+ * next assign / project / vqhip_prepare call rebuilds them.
+ *   VQHIP_OPT_RANKING     where candidates are ranked: VQHIP_VALUE_BF16 = split-bf16 products ("bf16x3"), VQHIP_VALUE_F32
+ *   VQHIP_OPT_PROJECTION  where y = Omega x is computed: VQHIP_VALUE_BF16 = six bf16 piece products ("bf16x6", needs the
+ *                         bf16 ranking too), VQHIP_VALUE_F32
+ *   VQHIP_VALUE_DEFAULT   bf16 for both, unless the process environment holds VQHIP_NO_BF (both f32) or VQHIP_NO_BF_PROJ
+ *                         (projection f32): the environment only moves the default, an explicit value always wins. */
+typedef enum { VQHIP_OPT_RANKING = 0, VQHIP_OPT_PROJECTION = 1 } vqhip_option;
+typedef enum { VQHIP_VALUE_DEFAULT = 0, VQHIP_VALUE_F32 = 1, VQHIP_VALUE_BF16 = 2 } vqhip_option_value;
+int vqhip_set_option(vqhip_ctx *ctx, int option /* vqhip_option */, int value /* vqhip_option_value */);
+
 /* ---- the hot path ------------------------------------------------------------------------ */
 
 /* find_closest_prototype for N samples (src/helpers.rs:55-77; local Omegas:
@@ -159,6 +172,7 @@ int vqhip_multi_set_prototypes(vqhip_multi *m, const float *W, uint32_t K, uint3
 int vqhip_multi_set_labels(vqhip_multi *m, const uint32_t *cls, uint32_t K);
 int vqhip_multi_set_omega(vqhip_multi *m, const float *Om, uint32_t M, uint32_t D);
 int vqhip_multi_set_local_omegas(vqhip_multi *m, const float *Oms, uint32_t K, uint32_t M, uint32_t D);
+int vqhip_multi_set_option(vqhip_multi *m, int option, int value);
 int vqhip_multi_assign(vqhip_multi *m, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out);
 int vqhip_multi_assign_rows_f64(vqhip_multi *m, const double *const *rows, uint64_t N, uint32_t D, uint32_t *idx_out,
                                 float *dist_out);
@@ -200,8 +214,8 @@ int vqhip_assign_matched_f64(vqhip_ctx *ctx, const double *X, const uint32_t *y,
 const char *vqhip_last_kernel(const vqhip_ctx *ctx);
 
 /* Where the last assign call ranked its candidates: "f32" (v_mfma_f32_32x32x2_f32), "bf16x3" (every f32 operand split
- * into two bf16 pieces, three piece products on v_mfma_f32_32x32x16_bf16; the environment variable VQHIP_NO_BF turns
- * it off) or "none" (kernels without a ranking stage: direct, local, scalar).  Ranking only picks the candidates: the
+ * into two bf16 pieces, three piece products on v_mfma_f32_32x32x16_bf16; vqhip_set_option(VQHIP_OPT_RANKING, VQHIP_VALUE_F32)
+ * turns it off) or "none" (kernels without a ranking stage: direct, local, scalar).  Ranking only picks the candidates: the
  * winners and distances that come back are measured in f32 in the reference's direct form either way, and an in-kernel
  * guard sends every sample whose ranking could be wrong to an exact scan, so both settings return the same results. */
 const char *vqhip_last_ranking(const vqhip_ctx *ctx);
@@ -209,7 +223,7 @@ const char *vqhip_last_ranking(const vqhip_ctx *ctx);
 /* Where the last assign call computed the projection y = Omega x of the Omega models (src/helpers.rs:41-43): "f32"
  * (v_mfma_f32_32x32x2_f32 / 16x16x4), "bf16x6" (Omega and x each split into three bf16 pieces that add up to the f32
  * value exactly, the six piece products down to 2^-16 of the leading one on v_mfma_f32_32x32x16_bf16, accumulated in
- * f32: measured at or below the f32 chain's error, tools/bf16x6_probe.hip; VQHIP_NO_BF_PROJ turns it off) or "none"
+ * f32: measured at or below the f32 chain's error, tools/bf16x6_probe.hip; vqhip_set_option(VQHIP_OPT_PROJECTION, VQHIP_VALUE_F32) turns it off) or "none"
  * (Euclidean models).  Unlike the ranking this is part of the result: the distances are measured on this y, to the
  * same 1e-5 bar against the f64 oracle either way. */
 const char *vqhip_last_projection(const vqhip_ctx *ctx);

@@ -176,7 +176,7 @@ int main()
         std::string why;
         hipError_t herr = hipSuccess;
         const std::vector<float> W = uniform(256 * 128, 9);
-        EngineModel *e = engine_build(W, 256, 128, std::vector<float>(), OMEGA_NONE, 0, std::vector<uint32_t>(), why, herr);
+        EngineModel *e = engine_build(W, 256, 128, std::vector<float>(), OMEGA_NONE, 0, std::vector<uint32_t>(), BuildOptions(), why, herr);
         if (e) engine_free(e);                                                              // (a GPU was present after all)
         else CHECK(herr != hipSuccess || !why.empty());
     }

@@ -157,6 +157,11 @@ OFFSET_MODELS = [
     ("liramlvq_16x256", 256, 1024, 16, "global", "mfma_omega_lowrank_lds"),
     ("gmlvq_k600_streamed", 128, 600, 128, "global", "mfma_omega"),
     ("lgmlvq_8x64", 64, 8, 64, "local", "mfma_local_bf16"),
+    # rows above 256 values: the long-row kernels subtract the centre from every chunk they fetch (kernels_long.hip)
+    ("glvq_d784_k50_long", 784, 50, 0, "none", "mfma_euclid_long"),
+    ("glvq_d300_k300_long_groups", 300, 300, 0, "none", "mfma_euclid_long"),     # two groups of 8 tiles: the rows walked twice
+    ("liramlvq_16x784_long", 784, 40, 16, "global", "mfma_omega_long"),
+    ("lgmlvq_5x10x300_long", 300, 5, 10, "local", "mfma_local_long"),
 ]
 
 
@@ -197,13 +202,25 @@ def test_offset_data_exact_hits(ctx):
 
 
 def test_unit_interval_data(ctx):
-    """Data in [0, 1) (pixel intensities): mean 0.5 in every dimension, the shift is on; 1e-5 bar, no floor."""
+    """Data in [0, 1) (pixel intensities): mean 0.5 in every dimension, the shift is on; 1e-5 bar, no floor.  D = 784 is
+    the textbook LVQ input (28 x 28 pixels) and runs on the long-row kernels; plain and matched."""
     rng = np.random.default_rng(8)
-    for D, K, M in ((128, 256, 0), (128, 256, 128), (256, 512, 16)):
+    for D, K, M, kind, kernel in ((128, 256, 0, "none", "mfma_euclid_lds_pipe"), (128, 256, 128, "global", "mfma_omega_lds"),
+                                  (256, 512, 16, "global", "mfma_omega_lowrank_lds"), (784, 50, 0, "none", "mfma_euclid_long"),
+                                  (1024, 100, 0, "none", "mfma_euclid_long"), (784, 40, 16, "global", "mfma_omega_long"),
+                                  (300, 5, 10, "local", "mfma_local_long")):
         W = rng.uniform(0, 1, size=(K, D)).astype(np.float32)
-        X = rng.uniform(0, 1, size=(1200 if M == 0 else 400, D)).astype(np.float32)
-        Om = None if M == 0 else (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
-        _check(ctx, X, W, Om=Om, atol=0.0)
+        N = 1200 if M == 0 else 400
+        X = rng.uniform(0, 1, size=(N, D)).astype(np.float32)
+        Om = None
+        if kind == "global":
+            Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+        elif kind == "local":
+            Om = (rng.uniform(-1, 1, size=(K, M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+        cls = (np.arange(K) % 3).astype(np.uint32)
+        y = rng.integers(0, 3, size=N).astype(np.uint32)
+        _check(ctx, X, W, Om=Om, cls=cls, y=y, atol=0.0, want_prefix=kernel)
+        assert ctx.last_kernel == kernel
 
 
 # ------------------------------------------------------------------ exact multi-way ties

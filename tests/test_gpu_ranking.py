@@ -1,14 +1,13 @@
 """GPU: ranking the candidates on the bf16 matrix cores changes nothing that leaves the library.
 
 The LDS-resident kernels rank prototypes by ||w||^2 - 2 x.w with every f32 operand split into two bf16 pieces and three
-piece products on v_mfma_f32_32x32x16_bf16 (mfma_device.h search_tiles_bf); VQHIP_NO_BF (read when a model's images
-are built) keeps the ranking on v_mfma_f32_32x32x2_f32.  Either way the best two candidates are re-measured in f32 in
+piece products on v_mfma_f32_32x32x16_bf16 (mfma_device.h search_tiles_bf); vqhip_set_option(VQHIP_OPT_RANKING,
+VQHIP_VALUE_F32) keeps the ranking on v_mfma_f32_32x32x2_f32.  Either way the best two candidates are re-measured in f32 in
 the reference's direct form (src/helpers.rs:18-23) and a third key within the ranking's margin sends the sample to the
 exact in-order scan (src/helpers.rs:55-77), so winners AND distances must agree bit for bit between the two settings --
 on easy data, on dense clusters where the guard does the work, on wide-range data where the bf16 pieces are at their
 worst, plain and matched.  (Against the f64 oracle both are held to the usual bar by the other GPU tests, which run with
 the default, bf16 ranking.)"""
-import os
 import zlib
 
 import numpy as np
@@ -16,16 +15,22 @@ import pytest
 
 import oracle
 import parity
-from vq_amd import KERNEL_AUTO, Context
+from vq_amd import KERNEL_AUTO, OPT_PROJECTION, OPT_RANKING, VALUE_BF16, VALUE_F32, Context
+
+# option settings of a run (vqhip_set_option): everything on the f32 cores / ranking on bf16, projection f32 / both on bf16
+ALL_F32 = {OPT_RANKING: VALUE_F32, OPT_PROJECTION: VALUE_F32}
+RANK_BF16 = {OPT_RANKING: VALUE_BF16, OPT_PROJECTION: VALUE_F32}
+ALL_BF16 = {OPT_RANKING: VALUE_BF16, OPT_PROJECTION: VALUE_BF16}
 
 pytestmark = pytest.mark.gpu
 
 
-def _run(X, W, Om, cls, y, env):
-    os.environ.update(env)
+def _run(X, W, Om, cls, y, options):
+    ctx = Context(0)
     try:
-        ctx = Context(0)
         ctx.set_kernel_policy(KERNEL_AUTO)
+        for opt, value in options.items():
+            ctx.set_option(opt, value)
         ctx.set_prototypes(W)
         if Om is not None:
             ctx.set_omega(Om)
@@ -34,11 +39,9 @@ def _run(X, W, Om, cls, y, env):
         ctx.set_labels(cls)
         out["matched"] = ctx.assign_matched(X, y)
         assert ctx.last_ranking == out["ranking"] and ctx.last_projection == out["projection"]
-        ctx.close()
         return out
     finally:
-        for k in env:
-            os.environ.pop(k, None)
+        ctx.close()
 
 
 def _data(kind, rng, N, K, D):
@@ -90,8 +93,8 @@ def test_bf16_ranking_returns_the_f32_rankings_results(shape, kind):
     y = rng.integers(0, 3, size=N).astype(np.uint32)
     # the projection is part of the result (vqhip_last_projection), the ranking is not: the rankings are compared with
     # the projection held on the f32 matrix cores; the bf16x6 projection is checked against the oracle below
-    bf = _run(X, W, Om, cls, y, {"VQHIP_NO_BF_PROJ": "1"})
-    f32 = _run(X, W, Om, cls, y, {"VQHIP_NO_BF": "1"})
+    bf = _run(X, W, Om, cls, y, RANK_BF16)
+    f32 = _run(X, W, Om, cls, y, ALL_F32)
     assert bf["kernel"] == kernel and f32["kernel"] == kernel, (bf["kernel"], f32["kernel"])
     assert bf["ranking"] == "bf16x3" and f32["ranking"] == "f32", (bf["ranking"], f32["ranking"])
     assert bf["projection"] == f32["projection"] == ("f32" if M else "none")
@@ -100,7 +103,7 @@ def test_bf16_ranking_returns_the_f32_rankings_results(shape, kind):
     for a, b, what in zip(bf["matched"], f32["matched"], ("j+", "d+", "j-", "d-")):
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32)), f"matched {what} differs"
     if kernel == "mfma_omega_lds":      # the default: ranking AND projection on the bf16 matrix cores
-        bf = _run(X, W, Om, cls, y, {})
+        bf = _run(X, W, Om, cls, y, ALL_BF16)
         assert bf["kernel"] == kernel and bf["ranking"] == "bf16x3" and bf["projection"] == "bf16x6", bf
         # against the f32 projection: the winner's distance agrees to the oracle's bar whichever index carries it, and
         # the index differs only where two prototypes are that close (near-ties)
@@ -128,7 +131,7 @@ LOCAL_SHAPES = [(128, 8, 128), (64, 8, 64), (256, 5, 40), (200, 3, 33), (32, 16,
 @pytest.mark.parametrize("shape", LOCAL_SHAPES, ids=lambda s: "x".join(map(str, s)))
 def test_local_projection_on_the_bf16_cores_against_the_f32_engine(shape):
     """LGMLVQ (src/lgmlvq/lgmlvq.rs:436-506): k_local_pj (six bf16 piece products per product) against k_engine<LOCAL> (f32 MFMA,
-    VQHIP_NO_BF_PROJ) on the same model -- distances to rounding, winners up to near-ties -- and both against the f64 oracle."""
+    VQHIP_OPT_PROJECTION = VQHIP_VALUE_F32) on the same model -- distances to rounding, winners up to near-ties -- and both against the f64 oracle."""
     D, K, M = shape
     rng = np.random.default_rng(zlib.crc32(f"local-{D}-{K}-{M}".encode()))
     N = 2500
@@ -138,25 +141,24 @@ def test_local_projection_on_the_bf16_cores_against_the_f32_engine(shape):
     cls = (np.arange(K) % 3).astype(np.uint32)
     y = rng.integers(0, 3, size=N).astype(np.uint32)
 
-    def run(env):
-        os.environ.update(env)
+    def run(options):
+        ctx = Context(0)
         try:
-            ctx = Context(0)
             ctx.set_kernel_policy(KERNEL_AUTO)
             ctx.set_prototypes(W)
             ctx.set_local_omegas(Oms)
+            for opt, value in options.items():            # after the model: setting an option drops the images like any set_*
+                ctx.set_option(opt, value)
             idx, dist = ctx.assign(X)
             out = (ctx.last_kernel, ctx.last_projection, idx, dist)
             ctx.set_labels(cls)
             out += (ctx.assign_matched(X, y),)
-            ctx.close()
             return out
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            ctx.close()
 
-    kb, pb, ib, db, mb = run({})
-    kf, pf, i32, d32, m32 = run({"VQHIP_NO_BF_PROJ": "1"})
+    kb, pb, ib, db, mb = run(ALL_BF16)
+    kf, pf, i32, d32, m32 = run(RANK_BF16)
     assert (kb, pb) == ("mfma_local_bf16", "bf16x6") and (kf, pf) == ("mfma_local", "f32"), (kb, pb, kf, pf)
     for j, d, fj, fd in ((ib, db, i32, d32), (mb[0], mb[1], m32[0], m32[1]), (mb[2], mb[3], m32[2], m32[3])):
         d, fd = np.asarray(d, dtype=np.float64), np.asarray(fd, dtype=np.float64)

@@ -1,0 +1,112 @@
+"""Rates on the inputs the in-kernel guard (third key, exact scan / crowded list) exists for -- not part of the contract.
+
+    python tools/guard_bench.py [case ...]      # default: all cases; results as one line each
+
+Cases ("the guard's price where it fires"):
+  synth_c2      config 2's own clustered data (the uncrowded rate everything else is compared with)
+  random_c2     uniform random prototypes and samples, K = 256, D = 128
+  init_state    the reference's initial state (src/lvq/lvq.rs:120): 8 classes x 12 prototypes on a line +-0.1, D = 64
+  clustered_256 / clustered_2048   clusters of 3-5 prototypes 1e-3 ||w|| apart, samples 3e-3 ||w|| from a cluster
+  binary_256    0 / 1 features, K = 256, D = 128 (exact multi-way ties)
+  random_1024 / random_4096        uniform random, streamed engine
+  pixels_784 / pixels_1024         data in [0, 1), K = 50 / 100: the long-row kernels with the centre subtracted
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from vq_amd import Context, synth
+
+
+def clustered(rng, K, D, spread_rel):
+    W = np.empty((K, D), dtype=np.float32)
+    centres = []
+    k = 0
+    while k < K:
+        m = min(int(rng.choice((3, 4, 5))), K - k)
+        c = rng.uniform(-1, 1, size=D)
+        step = spread_rel * np.linalg.norm(c)
+        for _ in range(m):
+            u = rng.normal(size=D)
+            W[k] = (c + step * u / np.linalg.norm(u)).astype(np.float32)
+            centres.append(c)
+            k += 1
+    return W, np.array(centres)
+
+
+def make(case, rng, n_host):
+    """-> (W, X_host block that is tiled on the device)"""
+    if case == "random_c2":
+        return rng.uniform(-1, 1, (256, 128)).astype(np.float32), rng.uniform(-1, 1, (n_host, 128)).astype(np.float32)
+    if case == "init_state":
+        D, classes, per = 64, 8, 12
+        means = rng.uniform(-1, 1, size=(classes, D))
+        W = np.concatenate([means[c] + rng.uniform(-0.1, 0.1, size=(per, 1)) for c in range(classes)]).astype(np.float32)
+        X = (means[rng.integers(0, classes, size=n_host)] + 0.3 * rng.uniform(-1, 1, size=(n_host, D))).astype(np.float32)
+        return W, X
+    if case.startswith("clustered_"):
+        K, D = int(case.split("_")[1]), 128
+        W, centres = clustered(rng, K, D, 1e-3)
+        pick = rng.integers(0, K, size=n_host)
+        u = rng.normal(size=(n_host, D))
+        u /= np.linalg.norm(u, axis=1, keepdims=True)
+        return W, (centres[pick] + 3e-3 * np.linalg.norm(centres[pick], axis=1, keepdims=True) * u).astype(np.float32)
+    if case == "binary_256":
+        return (rng.uniform(size=(256, 128)) < 0.5).astype(np.float32), (rng.uniform(size=(n_host, 128)) < 0.5).astype(np.float32)
+    if case.startswith("random_"):
+        K = int(case.split("_")[1])
+        return rng.uniform(-1, 1, (K, 128)).astype(np.float32), rng.uniform(-1, 1, (n_host, 128)).astype(np.float32)
+    if case.startswith("pixels_"):
+        D = int(case.split("_")[1])
+        K = 50 if D == 784 else 100
+        return rng.uniform(0, 1, (K, D)).astype(np.float32), rng.uniform(0, 1, (n_host, D)).astype(np.float32)
+    raise SystemExit(f"unknown case {case}")
+
+
+CASES = ["synth_c2", "random_c2", "init_state", "clustered_256", "clustered_2048", "binary_256", "random_1024", "random_4096",
+         "pixels_784", "pixels_1024"]
+
+
+def main():
+    cases = sys.argv[1:] or CASES
+    ctx = Context(0)
+    for case in cases:
+        rng = np.random.default_rng(abs(hash(case)) % (1 << 31))
+        if case == "synth_c2":
+            m = synth.make_model(synth.CONFIGS["c2"])
+            synth.load_model(ctx, m)
+            N = 4_000_000
+            X = synth.samples_device(ctx, m, 0, N)
+        else:
+            n_host = 262_144
+            W, Xh = make(case, rng, n_host)
+            D = W.shape[1]
+            reps = max(1, min(16, int(2.0e9 // (n_host * D * 4))))
+            if W.shape[0] >= 2048:
+                reps = min(reps, 4)
+            ctx.set_prototypes(W)
+            X = torch.from_numpy(Xh).cuda().repeat(reps, 1).contiguous()
+            N = X.shape[0]
+        idx = torch.empty(N, dtype=torch.int32, device="cuda")
+        dist = torch.empty(N, dtype=torch.float32, device="cuda")
+        ctx.assign_into(X, idx, dist)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        steps = 3
+        ev[0].record()
+        for _ in range(steps):
+            ctx.assign_into(X, idx, dist)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1]) / steps
+        print(f"{case:16s} kernel={ctx.last_kernel:26s} N={N:9d} K={ctx.K:5d} D={ctx.D:5d} ms={ms:9.3f} samples/s={N / ms * 1e3:.4g}", flush=True)
+        del X, idx, dist
+        torch.cuda.empty_cache()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,8 @@ LIB_PATH = os.environ.get("VQHIP_LIB") or os.path.join(_HERE, "libvqhip.so")
 OK, ERR_INVALID, ERR_STATE, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA = 0, 1, 2
 PROJECT_OMEGA, PROJECT_LAMBDA = 0, 1
+OPT_RANKING, OPT_PROJECTION = 0, 1
+VALUE_DEFAULT, VALUE_F32, VALUE_BF16 = 0, 1, 2
 
 # name -> (restype, argtypes); the single list the symbol-export test walks too
 _f, _u, _v = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p
@@ -23,6 +25,7 @@ SIGNATURES = {
     "vqhip_set_omega": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32]),
     "vqhip_set_local_omegas": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vqhip_set_kernel_policy": (C.c_int, [_v, C.c_int]),
+    "vqhip_set_option": (C.c_int, [_v, C.c_int, C.c_int]),
     "vqhip_assign": (C.c_int, [_v, _f, C.c_uint64, _u, _f]),
     "vqhip_assign_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), C.c_uint64, C.c_uint32, _u, _f]),
     "vqhip_project": (C.c_int, [_v, _f, C.c_uint64, C.c_int, _f]),
@@ -48,6 +51,7 @@ SIGNATURES = {
     "vqhip_multi_set_labels": (C.c_int, [_v, _u, C.c_uint32]),
     "vqhip_multi_set_omega": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32]),
     "vqhip_multi_set_local_omegas": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "vqhip_multi_set_option": (C.c_int, [_v, C.c_int, C.c_int]),
     "vqhip_multi_assign": (C.c_int, [_v, _f, C.c_uint64, _u, _f]),
     "vqhip_multi_assign_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), C.c_uint64, C.c_uint32, _u, _f]),
     "vqhip_multi_assign_matched": (C.c_int, [_v, _f, _u, C.c_uint64, _u, _f, _u, _f]),

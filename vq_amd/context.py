@@ -94,6 +94,10 @@ class Context:
     def set_kernel_policy(self, policy: int):
         self._chk(self._L.vqhip_set_kernel_policy(self._h, int(policy)))
 
+    def set_option(self, option: int, value: int):
+        """vqhip_set_option: OPT_RANKING / OPT_PROJECTION -> VALUE_DEFAULT / VALUE_F32 / VALUE_BF16 (images are rebuilt)."""
+        self._chk(self._L.vqhip_set_option(self._h, int(option), int(value)))
+
     @property
     def last_kernel(self) -> str:
         return self._L.vqhip_last_kernel(self._h).decode()

@@ -65,6 +65,7 @@ struct vqhip_ctx {
     const char *last_ranking = "none";
     const char *last_projection = "none";
     int policy = VQHIP_KERNEL_AUTO;
+    int opt_ranking = VQHIP_VALUE_DEFAULT, opt_projection = VQHIP_VALUE_DEFAULT;   // vqhip_set_option
 
     uint32_t K = 0, D = 0, M = 0;
     int omega_kind = OMEGA_NONE;
@@ -224,6 +225,18 @@ int upload(vqhip_ctx *c, T **dst, const T *src, size_t count)
 
 int prepare_project(vqhip_ctx *c);
 
+// vqhip_set_option resolved: an explicit value wins; VQHIP_VALUE_DEFAULT is the bf16 matrix cores unless the environment
+// says otherwise (VQHIP_NO_BF: nothing there; VQHIP_NO_BF_PROJ: the ranking only) -- the environment is a default, read
+// when a model's images are built, never an override.
+BuildOptions build_options(const vqhip_ctx *c)
+{
+    BuildOptions o;
+    const bool env_no_bf = getenv("VQHIP_NO_BF") != nullptr, env_no_pj = env_no_bf || getenv("VQHIP_NO_BF_PROJ") != nullptr;
+    o.bf_rank = c->opt_ranking == VQHIP_VALUE_DEFAULT ? !env_no_bf : c->opt_ranking == VQHIP_VALUE_BF16;
+    o.bf_proj = c->opt_projection == VQHIP_VALUE_DEFAULT ? !env_no_pj : c->opt_projection == VQHIP_VALUE_BF16;
+    return o;
+}
+
 // Makes sure the MFMA engine's tile images exist when the policy wants them.
 int prepare_engine(vqhip_ctx *c)
 {
@@ -231,7 +244,7 @@ int prepare_engine(vqhip_ctx *c)
     if (!c->engine_tried) {
         c->engine_tried = true;
         hipError_t herr = hipSuccess;
-        c->engine = engine_build(c->hW, c->K, c->D, c->hOm, c->omega_kind, c->M, c->hcls, c->engine_why, herr);
+        c->engine = engine_build(c->hW, c->K, c->D, c->hOm, c->omega_kind, c->M, c->hcls, build_options(c), c->engine_why, herr);
         if (herr != hipSuccess) return c->fail_hip(herr, "engine_build");
     }
     if (!c->engine && !c->engine2_tried && c->omega_kind == OMEGA_GLOBAL && !getenv("VQHIP_NO_TWO_PASS")) {
@@ -241,7 +254,7 @@ int prepare_engine(vqhip_ctx *c)
         if (c->proj_long || c->proj_omega) {
             hipError_t herr = hipSuccess;
             std::string why2;
-            c->engine2 = engine_build(c->hP, c->K, c->M, std::vector<float>(), OMEGA_NONE, 0, c->hcls, why2, herr);
+            c->engine2 = engine_build(c->hP, c->K, c->M, std::vector<float>(), OMEGA_NONE, 0, c->hcls, build_options(c), why2, herr);
             if (herr != hipSuccess) return c->fail_hip(herr, "engine_build (projected space)");
             if (!c->engine2) c->engine_why += "; projected space: " + why2;
         }
@@ -486,14 +499,14 @@ int prepare_project(vqhip_ctx *c)
             for (uint32_t m = 0; m < c->M; ++m)
                 for (uint32_t d = 0; d < c->D; ++d) OmT[(size_t)d * c->M + m] = c->hOm[(size_t)m * c->D + d];
             if (c->M <= 256)
-                c->proj_back = project_build(OmT, c->D, c->M, herr);
+                c->proj_back = project_build(OmT, c->D, c->M, build_options(c), herr);
             else
                 c->proj_back_long = long_project_build(OmT, c->D, c->M, herr);
             if (herr != hipSuccess) return c->fail_hip(herr, "project_build (Omega^T)");
         }
         return VQHIP_OK;
     }
-    c->proj_omega = project_build(c->hOm, c->M, c->D, herr);
+    c->proj_omega = project_build(c->hOm, c->M, c->D, build_options(c), herr);
     if (herr != hipSuccess) return c->fail_hip(herr, "project_build");
     if (!c->proj_omega) return VQHIP_OK;
     const uint32_t D = c->D, M = c->M;
@@ -504,7 +517,7 @@ int prepare_project(vqhip_ctx *c)
             for (uint32_t m = 0; m < M; ++m) t += (double)c->hOm[(size_t)m * D + i] * (double)c->hOm[(size_t)m * D + j];
             lam[(size_t)i * D + j] = lam[(size_t)j * D + i] = (float)t;
         }
-    c->proj_lambda = project_build(lam, D, D, herr);
+    c->proj_lambda = project_build(lam, D, D, build_options(c), herr);
     if (herr != hipSuccess) return c->fail_hip(herr, "project_build");
     return VQHIP_OK;
 }
@@ -895,6 +908,21 @@ try {
 }
 VQHIP_CATCH(c)
 
+int vqhip_set_option(vqhip_ctx *c, int option, int value)
+try {
+    if (!c) return VQHIP_ERR_INVALID;
+    if (value != VQHIP_VALUE_DEFAULT && value != VQHIP_VALUE_F32 && value != VQHIP_VALUE_BF16)
+        return c->fail(VQHIP_ERR_INVALID, "set_option: unknown value");
+    int *slot = option == VQHIP_OPT_RANKING ? &c->opt_ranking : option == VQHIP_OPT_PROJECTION ? &c->opt_projection : nullptr;
+    if (!slot) return c->fail(VQHIP_ERR_INVALID, "set_option: unknown option");
+    if (*slot == value) return VQHIP_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    drop_engine(c);                                       // the images depend on it: rebuilt by the next call, like after any vqhip_set_*
+    *slot = value;
+    return VQHIP_OK;
+}
+VQHIP_CATCH(c)
+
 int vqhip_assign(vqhip_ctx *c, const float *X, uint64_t N, uint32_t *idx_out, float *dist_out)
 try {
     if (!c) return VQHIP_ERR_INVALID;
@@ -1203,6 +1231,13 @@ int vqhip_multi_set_local_omegas(vqhip_multi *m, const float *Oms, uint32_t K, u
 try {
     if (!m) return VQHIP_ERR_INVALID;
     return on_all(m, [=](vqhip_ctx *c, size_t) { return vqhip_set_local_omegas(c, Oms, K, M, D); }, false);
+}
+VQHIP_CATCH_MULTI(m)
+
+int vqhip_multi_set_option(vqhip_multi *m, int option, int value)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    return on_all(m, [=](vqhip_ctx *c, size_t) { return vqhip_set_option(c, option, value); }, false);
 }
 VQHIP_CATCH_MULTI(m)
 

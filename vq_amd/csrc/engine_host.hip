@@ -40,6 +40,7 @@ struct EngineModel {
     float ss_limit = 0.0f, wmax2 = 0.0f, mscale = 6.103515625e-05f;
     bool bf = false;                  // k_resident_pipe: screening products on the bf16 matrix cores (mscale is then that path's)
     bool pj = false;                  // Omega kernels: the projection on the bf16 matrix cores too (img1 = three bf16 pieces per value)
+    BuildOptions opt;                 // what the caller allows on the bf16 matrix cores (vqhip_set_option)
 };
 
 namespace {
@@ -182,9 +183,11 @@ std::vector<float> bf_tiles_for(const EngineModel &m, const std::vector<float> &
 
 void set_bf(EngineModel &m, int R)
 {
-    if (getenv("VQHIP_NO_BF")) return;
+    if (!m.opt.bf_rank) return;
     m.bf = true;
-    m.mscale = (float)(6.0 / 65536.0 + 4.0 * (8.0 * std::sqrt(3.0 * R) * 5.9604644775390625e-08 + 1.9073486328125e-06));
+    // (the second form: the worst case of the f32 accumulation of 3 R products, which the first exceeds up to R = 128)
+    m.mscale = (float)(6.0 / 65536.0 + std::max(4.0 * (8.0 * std::sqrt(3.0 * R) * 5.9604644775390625e-08 + 1.9073486328125e-06),
+                                                2.0 * 3.0 * R * 5.9604644775390625e-08 + 3.814697265625e-06));
 }
 
 template <int R1>
@@ -413,7 +416,7 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     m.samples_per_batch = 32;
     m.name = "mfma_omega_lds";
     set_bf(m, R);
-    if (m.bf && !getenv("VQHIP_NO_BF_PROJ")) {
+    if (m.bf && m.opt.bf_proj) {
         // the projection on the bf16 matrix cores: piece (step q of 16 reduction values, tile t) at q * NT + t holds, for
         // lane (row, h), the three bf16 pieces of Omega[32 t + row][16 q + 4 h .. + 3] and [16 q + 8 + 4 h .. + 3]: 1 KiB of
         // first pieces (16 bytes per lane), 1 KiB of second, 1 KiB of third
@@ -486,7 +489,7 @@ template <int R1>
 bool bind_local_pj(EngineModel &m, std::vector<float> &img, const std::vector<float> &Oms, const std::vector<float> &negp,
                    const std::vector<uint32_t> &cls)
 {
-    if (m.R1 != (uint32_t)R1 || getenv("VQHIP_NO_BF") || getenv("VQHIP_NO_BF_PROJ")) return false;
+    if (m.R1 != (uint32_t)R1 || !m.opt.bf_rank || !m.opt.bf_proj) return false;
     int spb = 0;
     const LaunchFn fn = local_pj_launcher(R1, &spb);
     if (!fn) return false;
@@ -541,8 +544,8 @@ bool bind_local(EngineModel &m, std::vector<float> &img, const std::vector<float
 }  // namespace
 
 EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D, const std::vector<float> &Om,
-                          int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, std::string &why,
-                          hipError_t &herr)
+                          int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, const BuildOptions &opt,
+                          std::string &why, hipError_t &herr)
 {
     herr = hipSuccess;
     if (D > 256 && !(((omega_kind == OMEGA_NONE && (uint64_t)(K + 255) * (D + 127) * 4 < (1ull << 31)) || (omega_kind == OMEGA_GLOBAL && M <= 128) ||
@@ -556,14 +559,15 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         return nullptr;
     }
     EngineModel m;
+    m.opt = opt;
     m.K = K; m.D = D; m.M = M;
     m.R1 = D > 256 ? 0u : (uint32_t)pad_pow2(D, 16);
     m.has_cls = !cls.empty();
     std::vector<float> img1, img2, plain;
     bool ok = false;
 
-    // the coordinates everything below lives in: the caller's, or shifted by the mean prototype (centre_prototypes).
-    // Rows above 256 values keep the caller's coordinates (the long-row kernels fetch their rows in chunks, twice).
+    // the coordinates everything below lives in: the caller's, or shifted by the mean prototype (centre_prototypes);
+    // rows above 256 values included (the long-row kernels subtract the centre from every chunk they fetch)
     std::vector<float> mu, Wc;
     if (omega_kind == OMEGA_NONE && bind_direct(m, img1, Win, cls)) {         // nothing to screen, nothing to centre
         m.mode = MODE_EUCLID;
@@ -576,7 +580,7 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         }
         return out;
     }
-    const bool centred = D <= 256 && centre_prototypes(Win, K, D, mu, Wc);
+    const bool centred = centre_prototypes(Win, K, D, mu, Wc);
     const std::vector<float> &W = centred ? Wc : Win;
 
     if (omega_kind == OMEGA_NONE || omega_kind == OMEGA_GLOBAL) {
@@ -616,8 +620,11 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         // ||x||^2 below this: |2 x.w| <= 2 sqrt(ss wmax2) <= 1e18 and ||w||^2 + c stay far inside f32 range
         m.ss_limit = (float)std::min(1e36, 1e36 / (4.0 * std::max(wmax2, 1e-36)));
         m.wmax2 = (float)wmax2;
-        // screen_margin (mfma_device.h): twice the error of one key, reduction length L
-        m.mscale = (float)std::max(6.103515625e-05, 4.0 * (8.0 * std::sqrt((double)L) * 5.9604644775390625e-08 + 1.9073486328125e-06));
+        // screen_margin (mfma_device.h): twice the error of one key, reduction length L.  The last term is the worst case
+        // of the f32 fma chain (L 2^-24 of ||x||^2 + ||w||^2 per key, twice for a pair of keys, + the position bits): it
+        // takes over from the statistical middle term above L = 200, so the guarantee is one at every row length.
+        m.mscale = (float)std::max({6.103515625e-05, 4.0 * (8.0 * std::sqrt((double)L) * 5.9604644775390625e-08 + 1.9073486328125e-06),
+                                    2.0 * L * 5.9604644775390625e-08 + 3.814697265625e-06});
         if (omega_kind == OMEGA_NONE) {
             m.mode = MODE_EUCLID;
             m.name = "mfma_euclid";
@@ -713,7 +720,7 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
     if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
     if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
     if (herr == hipSuccess && centred) {
-        mu.resize(256, 0.0f);                                          // zero padded to the longest fragment a kernel reads
+        mu.resize(std::max<size_t>(256, ((size_t)D + 127) / 128 * 128), 0.0f);   // zero padded to the longest fragment / whole chunks a kernel reads
         herr = to_device(&out->mu, mu);
     }
     if (herr == hipSuccess) herr = hipMalloc((void **)&out->queue, QUEUE_SLOTS * QUEUE_STRIDE * sizeof(uint32_t));

@@ -26,9 +26,32 @@ struct RowWalker {
     uint64_t N;
     uint32_t D, row_bytes, voff;
     int h;
+    const float *mu = nullptr;            // the model's centre (EngineArgs::mu), zero padded to whole chunks; null: none
     __device__ __forceinline__ RowWalker(const float *X_, uint64_t N_, uint32_t D_, int s_col, int h_)
         : X(X_), N(N_), D(D_), row_bytes(D_ * 4u), voff((uint32_t)s_col * D_ * 4u + (uint32_t)h_ * 16u), h(h_)
     {
+    }
+    // x -= mu for chunk c, after cut() (mu is zero past D, so cleared values stay zero): one v_sub per value, the same
+    // f32 operation the host applied to the prototypes (centre_prototypes).  The centre's pieces come from L1 / L2 -- the
+    // 32 lanes of a half read the same 16 bytes -- as the chunk is worked: rows of this length leave neither registers
+    // to keep it nor (k_omega_long) LDS.
+    __device__ __forceinline__ void centre(f32x4 (&xs)[NJ], uint32_t c) const
+    {
+        if (mu == nullptr) return;
+        const uint32_t padded = (D + CHUNK - 1) / CHUNK * CHUNK;
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)mu, 0, (int)(padded * 4u), 0x00020000);
+        // two pieces at a time (the memory clobber keeps the next loads behind them): all NJ in flight at once would
+        // take NJ * 4 registers these kernels do not have
+#pragma unroll
+        for (int j0 = 0; j0 < NJ; j0 += 2) {
+            f32x4 m[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                m[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (uint32_t)h * 16u + (j0 + j) * 32, (int)(c * CHUNK * 4u), 0));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xs[j0 + j] = xs[j0 + j] - m[j];
+            asm volatile("" : "+v"(xs[j0]), "+v"(xs[j0 + 1])::"memory");
+        }
     }
     // num_records of a descriptor that starts at batch bb of an array with `unit` bytes per sample
     __device__ __forceinline__ uint32_t records(uint64_t bb, uint32_t unit) const
@@ -87,17 +110,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_long(const EngineArgs a)
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     queue.request();
 
-    const RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
+    RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
+    rows.mu = a.mu;                                    // centred model: both passes work on x - mu
     f32x4 xa[NJ], xb[NJ];                              // two chunks of the rows, worked alternately
     // fn(chunk registers, chunk number) over all chunks of batch bb; xa must hold (or be receiving) chunk 0
     auto for_chunks = [&](uint64_t bb, auto &&fn) {
         for (uint32_t c = 0; c < NC; c += 2) {
             if (c + 1 < NC) rows.fetch(xb, bb, c + 1);
             rows.cut(xa, c);
+            rows.centre(xa, c);
             fn(xa, c);
             if (c + 1 < NC) {
                 if (c + 2 < NC) rows.fetch(xa, bb, c + 2);
                 rows.cut(xb, c + 1);
+                rows.centre(xb, c + 1);
                 fn(xb, c + 1);
             }
         }
@@ -341,7 +367,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     queue.request();
 
-    const RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
+    RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
+    rows.mu = a.mu;                                    // centred model: y = Omega (x - mu), p_k = Omega (w_k - mu)
     f32x4 xa[NJ], xb[NJ];
     uint32_t ln[BLOCK];
 #pragma unroll
@@ -387,10 +414,12 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_long(const EngineArgs
             for (uint32_t c = 0; c < NC; c += 2) {
                 if (c + 1 < NC) rows.fetch(xb, b, c + 1);
                 rows.cut(xa, c);
+                rows.centre(xa, c);
                 mma(xa);
                 if (c + 1 < NC) {
                     if (c + 2 < NC) rows.fetch(xa, b, c + 2);
                     rows.cut(xb, c + 1);
+                    rows.centre(xb, c + 1);
                     mma(xb);
                 }
             }
@@ -462,7 +491,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_local_long(const EngineArgs
     uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
     queue.request();
 
-    const RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
+    RowWalker<NJ> rows(a.X, a.N, a.D, s_col, h);
+    rows.mu = a.mu;                                    // centred model: z = Omega_j (x - mu) - Omega_j (w_j - mu)
     f32x4 xa[NJ], xb[NJ];
     uint32_t ln[BLOCK];
 #pragma unroll
@@ -514,10 +544,12 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_local_long(const EngineArgs
                 for (uint32_t c = 0; c < NC; c += 2) {
                     if (c + 1 < NC) rows.fetch(xb, b, c + 1);
                     rows.cut(xa, c);
+                    rows.centre(xa, c);
                     mma(xa);
                     if (c + 1 < NC) {
                         if (c + 2 < NC) rows.fetch(xa, b, c + 2);
                         rows.cut(xb, c + 1);
+                        rows.centre(xb, c + 1);
                         mma(xb);
                     }
                 }

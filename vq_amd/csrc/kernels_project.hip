@@ -198,14 +198,14 @@ hipError_t launch_project_pj(const ProjectArgs &a, hipStream_t st)
 }
 
 template <int R>
-bool bind_project(ProjectModel &m, std::vector<float> &img, const std::vector<float> &A)
+bool bind_project(ProjectModel &m, std::vector<float> &img, const std::vector<float> &A, const BuildOptions &opt)
 {
     if (m.D > (uint32_t)R || (R > 32 && m.D <= (uint32_t)R / 2)) return false;       // narrowest instantiation that holds a row
     uint32_t ngroups = 0;
     m.R = R;
     m.ntiles = (m.rows + 31) / 32;
     if constexpr (R <= 128) {
-        if (!getenv("VQHIP_NO_BF") && !getenv("VQHIP_NO_BF_PROJ")) {
+        if (opt.bf_rank && opt.bf_proj) {
             img = build_images3<R>(A.data(), m.rows, m.D, m.D, nullptr, nullptr, ngroups);
             m.tile_floats = Geom3<R>::TILE_BYTES / 4;
             m.tiles_per_launch = (uint32_t)(RES_BYTES / Geom3<R>::TILE_BYTES);
@@ -222,14 +222,14 @@ bool bind_project(ProjectModel &m, std::vector<float> &img, const std::vector<fl
 }
 }  // namespace
 
-ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t D, hipError_t &herr)
+ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t D, const BuildOptions &opt, hipError_t &herr)
 {
     herr = hipSuccess;
     ProjectModel m;
     m.rows = rows;
     m.D = D;
     std::vector<float> img;
-    if (!(bind_project<32>(m, img, A) || bind_project<64>(m, img, A) || bind_project<128>(m, img, A) || bind_project<256>(m, img, A)))
+    if (!(bind_project<32>(m, img, A, opt) || bind_project<64>(m, img, A, opt) || bind_project<128>(m, img, A, opt) || bind_project<256>(m, img, A, opt)))
         return nullptr;
     ProjectModel *out = new ProjectModel(m);
     herr = to_device(&out->img, img);

@@ -65,10 +65,17 @@ hipError_t launch_assign_local_scalar(const float *dX, uint64_t N, uint32_t D, c
 // ---------------------------------------------------------------- MFMA kernels (engine_host.hip builds the model; kernels_engine / _resident / _omega.hip)
 struct EngineModel;   // device tile images + shapes, built by the engine from host copies
 
+// Where the matrix-core kernels may run their products (vqhip_set_option, include/vqhip.h; resolved against the
+// environment's defaults in api.cpp): the candidates' ranking as three bf16 piece products, the projections as six.
+struct BuildOptions {
+    bool bf_rank = true;
+    bool bf_proj = true;
+};
+
 // Returns nullptr (and sets why) when the shape is not eligible for the engine.
 EngineModel *engine_build(const std::vector<float> &W, uint32_t K, uint32_t D, const std::vector<float> &Om,
-                          int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, std::string &why,
-                          hipError_t &herr);
+                          int omega_kind, uint32_t M, const std::vector<uint32_t> &cls, const BuildOptions &opt,
+                          std::string &why, hipError_t &herr);
 void engine_free(EngineModel *m);
 const char *engine_name(const EngineModel *m);
 const char *engine_ranking(const EngineModel *m);     // "bf16x3" | "f32": where the candidates are ranked; "none": no ranking stage
@@ -80,7 +87,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
 
 // Y = X . A^T on the matrix cores for an A (rows x D) resident in LDS; nullptr when D is not 32/64/128/256.
 struct ProjectModel;
-ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t D, hipError_t &herr);
+ProjectModel *project_build(const std::vector<float> &A, uint32_t rows, uint32_t D, const BuildOptions &opt, hipError_t &herr);
 void project_free(ProjectModel *m);
 bool project_on_bf16(const ProjectModel *m);          // the products run as six bf16 piece products (Geom3 tiles)
 hipError_t project_run(const ProjectModel *m, const float *dX, uint64_t N, float *dY, uint32_t ldy, hipStream_t s);
