@@ -25,9 +25,9 @@ $(LIBA): $(OBJS)
 	rm -f $@ && ar rcs $@ $(OBJS)
 
 # the C++ mirror's tests linked against the ARCHIVE with plain g++, the way a Rust build would link it:
-# the archive + the HIP runtime + the C++ runtime, nothing else
+# the archive + the HIP runtime + RCCL (vqhip_multi_assign_device) + the C++ runtime, nothing else
 $(MODELS_TEST_STATIC): tests/cpp/test_models.cpp include/vq_models.hpp include/vqhip.h $(LIBA)
-	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ $(LIBA) -L$(ROCM_LIB) -lamdhip64 -lpthread -Wl,-rpath,$(ROCM_LIB)
+	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ $(LIBA) -L$(ROCM_LIB) -lamdhip64 -lrccl -lpthread -Wl,-rpath,$(ROCM_LIB)
 
 tools/hbm_stream: tools/hbm_stream.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
@@ -49,7 +49,7 @@ tests/cpp/test_host_asan: tests/cpp/test_host_asan.cpp $(CSRC)/engine_host.hip $
 	    -Iinclude -I$(CSRC) -DVQHIP_HOST_TEST $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -L$(ROCM_LIB) -lrccl
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

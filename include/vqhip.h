@@ -179,6 +179,19 @@ int vqhip_multi_assign_rows_f64(vqhip_multi *m, const double *const *rows, uint6
 int vqhip_multi_assign_matched(vqhip_multi *m, const float *X, const uint32_t *y, uint64_t N, uint32_t *jpos,
                                float *dpos, uint32_t *jneg, float *dneg);
 
+/* The same search for shards that LIVE on the GPUs, with the RCCL exchange of the results (north star: "RCCL over xGMI is
+ * used only to gather winner indices and distances"; the samples of `predict` are independent, src/glvq/glvq.rs:224-232).
+ * dX[g]: the shard of device g (n_rows[g] x D, on that device; global rows [first_g, first_g + n_rows[g]) with
+ * first_g = n_rows[0] + .. + n_rows[g-1]).  didx_all[g] / ddist_all[g]: arrays of sum(n_rows) elements ON device g.
+ * Every device searches its shard on its own stream into its own slice, then the slices are exchanged in place by one
+ * grouped ncclAllGather per array (equal shards; unequal ones: one ncclBroadcast per shard, grouped) over a
+ * single-process communicator clique (ncclCommInitAll) held by the handle -- so every device ends up with the winners
+ * of ALL samples.  ddist_all may be NULL.  Returns after all streams have drained.  A device listed twice in the handle:
+ * VQHIP_ERR_UNSUPPORTED (one rank per GPU).  Measured on one GPU only so far (a clique of one rank); the 8-GPU exchange
+ * is 8 bytes per sample against >= 520 bytes read. */
+int vqhip_multi_assign_device(vqhip_multi *m, const float *const *dX, const uint64_t *n_rows, uint32_t *const *didx_all,
+                              float *const *ddist_all);
+
 /* ---- projections ---------------------------------------------------------
  * project / project_omega for N samples.  X is N x D, row-major.
  *   VQHIP_PROJECT_OMEGA   Y = Omega x,  N x M   LiRaMLVQ::project_omega   src/liramlvq/liramlvq.rs:429-446

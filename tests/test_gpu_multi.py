@@ -54,6 +54,49 @@ def test_multi_handle_shards_and_matches_the_single_context(devices):
         MultiContext([99])
 
 
+def test_multi_device_resident_shards_gather_over_rccl():
+    """vqhip_multi_assign_device: device-resident shard -> search on the device's own stream -> RCCL exchange in place over the
+    handle's communicator clique (ncclCommInitAll).  One GPU here: a clique of one rank (the gather is the identity), equal and
+    "unequal" paths both run; the N > 1 exchange is unmeasured until an 8-GPU node runs it.  A device listed twice is refused
+    (RCCL wants one rank per GPU)."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    D, K, N = 128, 256, 20_011
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    one, m = Context(0), MultiContext([0])
+    try:
+        one.set_prototypes(W)
+        m.set_prototypes(W)
+        i1, d1 = one.assign(X)
+        Xd = torch.from_numpy(X).cuda()
+        for _ in range(2):                                                # twice: streams and communicator are reused
+            idx = torch.full((N,), -7, dtype=torch.int32, device="cuda")
+            dist = torch.full((N,), -7.0, dtype=torch.float32, device="cuda")
+            m.assign_device_shards([Xd], [idx], [dist])
+            assert (idx.cpu().numpy().view(np.uint32) == i1).all()
+            assert (dist.cpu().numpy().view(np.uint32) == d1.view(np.uint32)).all()
+        idx = torch.full((N,), -7, dtype=torch.int32, device="cuda")
+        m.assign_device_shards([Xd[:777]], [idx], None)                   # no distances; fewer rows than the arrays hold
+        got = idx.cpu().numpy()
+        assert (got[:777].view(np.uint32) == i1[:777]).all() and (got[777:] == -7).all()
+        m.assign_device_shards([Xd[:0]], [idx], None)                     # nothing to do
+    finally:
+        m.close()
+        one.close()
+    m2 = MultiContext([0, 0])
+    try:
+        m2.set_prototypes(W)
+        Xd = torch.from_numpy(X[:64]).cuda()
+        idx = [torch.empty(128, dtype=torch.int32, device="cuda") for _ in range(2)]
+        with pytest.raises(VqhipError) as e:
+            m2.assign_device_shards([Xd, Xd], idx, None)
+        assert e.value.code == -5 and "twice" in e.value.text
+    finally:
+        m2.close()
+
+
 def test_project_host_path_is_pipelined_over_chunks():
     """vqhip_project from host pointers: more rows than one pinned buffer holds (D = 8: 4M-row chunks), both projections."""
     rng = np.random.default_rng(4)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "vqhip_multi_set_local_omegas": (C.c_int, [_v, _f, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vqhip_multi_set_option": (C.c_int, [_v, C.c_int, C.c_int]),
     "vqhip_multi_assign": (C.c_int, [_v, _f, C.c_uint64, _u, _f]),
+    "vqhip_multi_assign_device": (C.c_int, [_v, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "vqhip_multi_assign_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), C.c_uint64, C.c_uint32, _u, _f]),
     "vqhip_multi_assign_matched": (C.c_int, [_v, _f, _u, C.c_uint64, _u, _f, _u, _f]),
     "vqhip_synth_fill_host": (C.c_int, [_f, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_float, _f, C.c_uint64]),
@@ -75,9 +76,10 @@ def _share_torch_hip_runtime():
     spec = importlib.util.find_spec("torch")
     if spec is None or not spec.submodule_search_locations:
         return
-    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(path):
-        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name in ("libamdhip64.so", "librccl.so"):        # librccl.so.1 is NEEDED by libvqhip.so as well (vqhip_multi_assign_device)
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def lib() -> C.CDLL:

@@ -371,6 +371,32 @@ class MultiContext:
         self._chk(self._L.vqhip_multi_assign_rows_f64(self._h, ptrs, N, self.D, _up(idx), _fp(dist)))
         return idx, dist
 
+    def assign_device_shards(self, shards, idx_all, dist_all=None):
+        """vqhip_multi_assign_device: shards[g] = CUDA float32 tensor (n_g x D) on device g of the handle; idx_all[g] /
+        dist_all[g] = int32 / float32 tensors of sum(n_g) elements on device g.  Every device ends up with all winners
+        (RCCL all-gather in place).  Returns after the exchange has completed."""
+        import torch
+
+        n = self.device_count
+        if len(shards) != n or len(idx_all) != n or (dist_all is not None and len(dist_all) != n):
+            raise ValueError("one shard and one result array per device of the handle")
+        total = sum(int(x.shape[0]) for x in shards)
+        for g in range(n):
+            x = shards[g]
+            if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and x.shape[1] == self.D):
+                raise ValueError(f"shard {g} must be a contiguous CUDA float32 n x {self.D} tensor")
+            outs = [(idx_all[g], torch.int32)] + ([(dist_all[g], torch.float32)] if dist_all is not None else [])
+            for t, dt in outs:
+                if not (t.is_cuda and t.device == x.device and t.dtype == dt and t.is_contiguous() and t.dim() == 1 and t.numel() >= total):
+                    raise ValueError(f"result arrays of device {g} must be contiguous 1-D tensors of {total} elements on the shard's device")
+        torch.cuda.synchronize()                     # the library works on streams of its own
+        vp = C.c_void_p * n
+        xs = vp(*[C.c_void_p(x.data_ptr()) for x in shards])
+        rows = (C.c_uint64 * n)(*[int(x.shape[0]) for x in shards])
+        ii = vp(*[C.c_void_p(t.data_ptr()) for t in idx_all])
+        dd = vp(*[C.c_void_p(t.data_ptr()) for t in dist_all]) if dist_all is not None else None
+        self._chk(self._L.vqhip_multi_assign_device(self._h, xs, rows, ii, dd))
+
     def assign_matched(self, X, y):
         X = np.ascontiguousarray(X, dtype=np.float32)
         y = np.ascontiguousarray(y, dtype=np.uint32)

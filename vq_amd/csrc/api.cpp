@@ -10,6 +10,8 @@
 #include <new>
 #include <thread>
 
+#include <rccl/rccl.h>
+
 #include "mfma_host.h"
 #include "vq_common.h"
 
@@ -1093,6 +1095,10 @@ VQHIP_CATCH(c)
 
 struct vqhip_multi {
     std::vector<vqhip_ctx *> ctx;
+    // device-resident shards (vqhip_multi_assign_device): one stream per context, and one RCCL communicator per device
+    // of a single-process clique (ncclCommInitAll), created by the first call that needs them
+    std::vector<hipStream_t> streams;
+    std::vector<ncclComm_t> comms;
     std::string err;
     int fail(int code, const std::string &msg)
     {
@@ -1196,6 +1202,11 @@ VQHIP_CATCH_MULTI(nullptr)
 int vqhip_multi_destroy(vqhip_multi *m)
 try {
     if (!m) return VQHIP_OK;
+    for (ncclComm_t comm : m->comms) (void)ncclCommDestroy(comm);
+    for (size_t g = 0; g < m->streams.size(); ++g) {
+        (void)hipSetDevice(m->ctx[g]->device);
+        (void)hipStreamDestroy(m->streams[g]);
+    }
     for (vqhip_ctx *c : m->ctx) (void)vqhip_destroy(c);
     delete m;
     return VQHIP_OK;
@@ -1250,6 +1261,96 @@ try {
         const Shard sh = shard_of(N, n, g);
         return vqhip_assign(c, X + sh.first * c->D, sh.rows, idx_out + sh.first, dist_out ? dist_out + sh.first : nullptr);
     }, true);
+}
+VQHIP_CATCH_MULTI(m)
+
+// ---- device-resident shards + the RCCL gather of the results (SURVEY.md section 8 row e) ---------------------------------
+namespace {
+// streams and the communicator clique of the handle's devices (once)
+int multi_device_setup(vqhip_multi *m)
+{
+    const size_t n = m->ctx.size();
+    if (m->streams.empty()) {
+        std::vector<hipStream_t> st(n, nullptr);
+        for (size_t g = 0; g < n; ++g) {
+            hipError_t e = hipSetDevice(m->ctx[g]->device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking);
+            if (e != hipSuccess) {
+                for (size_t k = 0; k < g; ++k) {
+                    (void)hipSetDevice(m->ctx[k]->device);
+                    (void)hipStreamDestroy(st[k]);
+                }
+                return m->fail(VQHIP_ERR_HIP, std::string("multi_assign_device: stream: ") + hipGetErrorString(e));
+            }
+        }
+        m->streams = st;
+    }
+    if (m->comms.empty()) {
+        std::vector<int> devs(n);
+        for (size_t g = 0; g < n; ++g) devs[g] = m->ctx[g]->device;
+        for (size_t g = 0; g < n; ++g)
+            for (size_t k = 0; k < g; ++k)
+                if (devs[g] == devs[k])
+                    return m->fail(VQHIP_ERR_UNSUPPORTED, "multi_assign_device: a device is listed twice (RCCL wants one rank per GPU); use the host-pointer calls");
+        std::vector<ncclComm_t> comms(n);
+        const ncclResult_t r = ncclCommInitAll(comms.data(), (int)n, devs.data());
+        if (r != ncclSuccess) return m->fail(VQHIP_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        m->comms = comms;
+    }
+    return VQHIP_OK;
+}
+}  // namespace
+
+int vqhip_multi_assign_device(vqhip_multi *m, const float *const *dX, const uint64_t *n_rows, uint32_t *const *didx_all,
+                              float *const *ddist_all)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    if (!dX || !n_rows || !didx_all) return m->fail(VQHIP_ERR_INVALID, "multi_assign_device: dX, n_rows or didx_all is NULL");
+    const size_t n = m->ctx.size();
+    std::vector<uint64_t> first(n + 1, 0);
+    bool equal = true;
+    for (size_t g = 0; g < n; ++g) {
+        if ((n_rows[g] && !dX[g]) || !didx_all[g]) return m->fail(VQHIP_ERR_INVALID, "multi_assign_device: a device's pointer is NULL");
+        if (ddist_all && !ddist_all[g]) return m->fail(VQHIP_ERR_INVALID, "multi_assign_device: a device's distance pointer is NULL");
+        first[g + 1] = first[g] + n_rows[g];
+        equal = equal && n_rows[g] == n_rows[0];
+    }
+    int rc = multi_device_setup(m);
+    if (rc != VQHIP_OK) return rc;
+    // every device searches its own shard into its own slice of its own copy of the result arrays ...
+    for (size_t g = 0; g < n; ++g) {
+        vqhip_ctx *c = m->ctx[g];
+        rc = vqhip_assign_device(c, dX[g], n_rows[g], didx_all[g] + first[g], ddist_all ? ddist_all[g] + first[g] : nullptr, m->streams[g]);
+        if (rc != VQHIP_OK) return m->fail(rc, "device " + std::to_string(c->device) + " (shard " + std::to_string(g) + "): " + c->err);
+    }
+    // ... and the slices are exchanged in place, behind the kernels on the same streams: one grouped all-gather per array
+    // (equal shards), or one broadcast per shard (the all-gather of unequal pieces).  8 bytes per sample over xGMI.
+    auto exchange = [&](auto *const *arrays, ncclDataType_t type) -> ncclResult_t {
+        ncclResult_t r = ncclGroupStart();
+        for (size_t g = 0; g < n && r == ncclSuccess; ++g) {
+            if (equal) {
+                r = ncclAllGather(arrays[g] + first[g], arrays[g], (size_t)n_rows[0], type, m->comms[g], m->streams[g]);
+            } else {
+                for (size_t root = 0; root < n && r == ncclSuccess; ++root)
+                    if (n_rows[root])
+                        r = ncclBroadcast(arrays[g] + first[root], arrays[g] + first[root], (size_t)n_rows[root], type, (int)root,
+                                          m->comms[g], m->streams[g]);
+            }
+        }
+        const ncclResult_t e = ncclGroupEnd();
+        return r != ncclSuccess ? r : e;
+    };
+    if (first[n] != 0) {
+        ncclResult_t r = exchange(didx_all, ncclUint32);
+        if (r == ncclSuccess && ddist_all) r = exchange(ddist_all, ncclFloat32);
+        if (r != ncclSuccess) return m->fail(VQHIP_ERR_HIP, std::string("RCCL gather: ") + ncclGetErrorString(r));
+    }
+    for (size_t g = 0; g < n; ++g) {
+        hipError_t e = hipSetDevice(m->ctx[g]->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->streams[g]);
+        if (e != hipSuccess) return m->fail(VQHIP_ERR_HIP, std::string("multi_assign_device: ") + hipGetErrorString(e));
+    }
+    return VQHIP_OK;
 }
 VQHIP_CATCH_MULTI(m)
 

@@ -777,6 +777,11 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
         if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
         a.dbg = dbg_buf;
     }
+    if (getenv("VQHIP_STATS") && !queue) {                            // experiment: event counters of the epilogue
+        if (!dbg_buf && hipMalloc((void **)&dbg_buf, 4096 * 4 * 8 * 8) != hipSuccess) dbg_buf = nullptr;
+        a.dbg = dbg_buf;
+        if (dbg_buf) (void)hipMemsetAsync(dbg_buf, 0, 256, s);
+    }
     a.queue = queue ? queue : m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
     a.mu = m->mu;
     a.mscale = m->mscale;
@@ -787,6 +792,12 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.pj = m->pj ? 1u : 0u;
     a.cls = m->cls;
     hipError_t e = m->launch(a, dy != nullptr, s);
+    if (a.dbg && e == hipSuccess && getenv("VQHIP_STATS")) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long h[8];
+        (void)hipMemcpy(h, a.dbg, sizeof h, hipMemcpyDeviceToHost);
+        fprintf(stderr, "stats: scans(wave) %llu scan_lanes %llu close(wave) %llu crowded_p %llu crowded_n %llu nonfinite %llu\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+    } else
     if (a.dbg && e == hipSuccess && getenv("VQHIP_DUMP")) {           // diagnostic: phase sums of this launch
         (void)hipStreamSynchronize(s);
         const size_t nw = 512 * 4;

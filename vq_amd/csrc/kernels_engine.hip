@@ -32,10 +32,14 @@ namespace vq {
 // silence).  The search stages screen with packed keys (4 VALU per score, see k_resident_pipe).
 // BF: the search stage's products on the bf16 matrix cores (tile_mma_ready, mfma_device.h): the search image then holds
 // the prototypes' bf16 pieces (nothing else reads its values: the exact re-measurement and scan go to a.plain); projections stay f32.
-template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, bool BF = false>
+// GRP (with BF): the keys stand for groups of four prototypes (GroupKeys / finish_groups, mfma_device.h): 1.5 VALU per score
+// instead of 4, four exact rows per candidate in the epilogue -- for models of many tiles, where the screening is most of
+// the instruction stream and the epilogue a small part of a batch.
+template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, bool BF = false, bool GRP = false>
 __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
 {
     static_assert(!BF || MODE != MODE_LOCAL, "LOCAL has no ranking stage");
+    static_assert(!GRP || BF, "group keys come with the bf16 ranking");
     using G1 = Geom<R1>;
     using G2 = Geom<MODE == MODE_OMEGA ? R2 : R1>;
     constexpr int RS = MODE == MODE_OMEGA ? R2 : R1;                 // reduction length of the search stage
@@ -281,7 +285,15 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                             ou[s] = ku[s];
                             om[s] = km[s];
                         }
-                        if constexpr (!MATCHED) {
+                        if constexpr (GRP) {
+#pragma unroll
+                            for (int s = 0; s < S; ++s) {
+                                GroupKeys<MATCHED> scr{ku[s], km[s]};
+                                scr.template tile<1>(acc[s], tile_id, tile + G2::W_FLOATS, lab[s], h);
+                                ku[s] = scr.ku;
+                                km[s] = scr.km;
+                            }
+                        } else if constexpr (!MATCHED) {
 #pragma unroll
                             for (int s = 0; s < S; ++s) {
                                 screen16<1>(acc[s], ku[s]);            // acc[s] is fresh from the matrix pipe
@@ -344,6 +356,12 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     }
                     return have;
                 };
+                if constexpr (GRP) {
+                    finish_groups<MATCHED>(
+                        h, unsafe[s], margin[s], ku[s], km[s], wp, wn, measure,
+                        [&](uint32_t k, bool positive) { return k < a.K && (!MATCHED || (a.cls[k] == lab[s]) == positive); },
+                        [&]() { exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn); });
+                } else {
                 if (!MATCHED) {
                     if (!group(ku[s].b1, ku[s].t1, ku[s].b2, ku[s].t2, ku[s].b3, wp)) rescan = true;
                 } else {
@@ -351,6 +369,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     group(km[s].n, km[s].tn, km[s].n2, km[s].tn2, km[s].n3, wn);
                 }
                 if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn);
+                }
             }
             if (live) {
                 if (h == 0) {
@@ -387,6 +406,18 @@ hipError_t launch_t(const EngineArgs &a, bool matched, hipStream_t st)
     const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
     if (e != hipSuccess) return e;
     if constexpr (MODE != MODE_LOCAL && (MODE == MODE_OMEGA ? R2 : R1) <= 128) {
+        // Group keys where a candidate's four rows are one or two fetches each (the exact rows come from L2 here, a round
+        // trip per row: at 128 values per row four of them cost a batch more than the cheaper screening returns --
+        // K = 1024: 6.6e8 samples/s against 7.3e8, K = 4096: 0.93e8 against 1.09e8)
+        if constexpr ((MODE == MODE_OMEGA ? R2 : R1) <= 32) {
+            if (a.bf && a.K > 15u * 32u) {
+                if (matched)
+                    hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS, true, true>), dim3(grid), dim3(256), 0, st, a);
+                else
+                    hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false, WPS, true, true>), dim3(grid), dim3(256), 0, st, a);
+                return hipGetLastError();
+            }
+        }
         if (a.bf) {
             if (matched)
                 hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS, true>), dim3(grid), dim3(256), 0, st, a);

@@ -167,18 +167,26 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
         const float margin = unsafe ? 0.0f : screen_margin(ss, a);
 
         // ---- search in the projected space (k_resident_pipe's tile loop at R = 16)
-        Keys2 ku;
-        KeysM km;
-        if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above stays f32
+        Best1 wp, wn;
+        if constexpr (BF) {
+            // The ranking on the bf16 matrix cores (search_tiles_bf; the projection above stays f32), the keys over groups
+            // of four prototypes: with 16 reduction values a tile is three MFMAs, and 4 VALU per score were three quarters
+            // of its instructions; re-measuring a group's four rows of 16 values costs the epilogue next to nothing.
+            GroupKeys<MATCHED> scr;
             u32x4 bh[1], bl[1];
             split_fragment<16>(yf, bh, bl);
-            search_tiles_bf<16, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, a.nbf);
+            search_tiles_bf<16>(img, ntiles, label, bh, bl, s_col, h, scr, bfimg, a.nbf);
+            auto cls_of = [&](uint32_t k) { return ((const uint32_t *)(img + (size_t)(k >> 5) * Gs::TILE_FLOATS + Gs::W_FLOATS))[32 + (k & 31)]; };
+            finish_groups<MATCHED>(
+                h, unsafe, margin, scr.ku, scr.km, wp, wn, [&](uint32_t k) { return exact_sq_lds<16>(yf, img, k, h); },      // squared: helpers.rs:44
+                [&](uint32_t k, bool positive) { return k < a.K && (!MATCHED || (cls_of(k) == label) == positive); },
+                [&]() { scan_exact_lds<16, MATCHED, false>(yf, img, a.K, label, h, wp, wn); }, a.dbg);
         } else {
+            Keys2 ku;
+            KeysM km;
             search_tiles<16, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
+            finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
         }
-
-        Best1 wp, wn;
-        finish_keys<16, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
         {
             const int rec = (int)records(b, 4u);
             const uint32_t so = (uint32_t)s_col * 4u;
@@ -401,15 +409,16 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         const float margin = unsafe ? 0.0f : screen_margin(ss, a);
 
         // ---- search in the projected space (k_resident_pipe's tile loop)
-        Keys2 ku;
-        KeysM km;
+        TopKeys<MATCHED> scr;
+        Keys2 &ku = scr.ku;
+        KeysM &km = scr.km;
         if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above: f32, or bf16x6 with PJ
             u32x4 bh[R / 16], bl[R / 16];
             split_fragment<R>(yf, bh, bl);
             if constexpr (BFIMG)
-                search_pieces<R, MATCHED>((const char *)img, (uint32_t)Gs::TILE_BYTES, img + Gs::W_FLOATS, ntiles, label, bh, bl, s_col, h, ku, km);
+                search_pieces<R>((const char *)img, (uint32_t)Gs::TILE_BYTES, img + Gs::W_FLOATS, ntiles, label, bh, bl, s_col, h, scr);
             else
-                search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, a.nbf);
+                search_tiles_bf<R>(img, ntiles, label, bh, bl, s_col, h, scr, bfimg, a.nbf);
         } else {
             search_tiles<R, MATCHED>(img, ntiles, label, yf, s_col, h, ku, km);
         }

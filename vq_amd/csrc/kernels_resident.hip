@@ -338,15 +338,16 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             if constexpr (STAGED) fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
             lap(1);                                    // 1: issue of the claim / of the staged variant's next pieces
 
-            Keys2 ku;
-            KeysM km;
+            TopKeys<MATCHED> scr;
+            Keys2 &ku = scr.ku;
+            KeysM &km = scr.km;
             if constexpr (BF) {
                 u32x4 bh[R / 16], bl[R / 16];
                 split_fragment<R>(xf, bh, bl);
                 if constexpr (BFIMG)
-                    search_pieces<R, MATCHED>((const char *)img, (uint32_t)Gm::TILE_BYTES, img + Gm::W_FLOATS, ntiles, label, bh, bl, s_col, h, ku, km);
+                    search_pieces<R>((const char *)img, (uint32_t)Gm::TILE_BYTES, img + Gm::W_FLOATS, ntiles, label, bh, bl, s_col, h, scr);
                 else
-                    search_tiles_bf<R, MATCHED>(img, ntiles, label, bh, bl, s_col, h, ku, km, bfimg, nbf);
+                    search_tiles_bf<R>(img, ntiles, label, bh, bl, s_col, h, scr, bfimg, nbf);
             } else {
                 search_tiles<R, MATCHED>(img, ntiles, label, xf, s_col, h, ku, km);
             }

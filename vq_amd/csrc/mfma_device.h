@@ -932,24 +932,133 @@ __device__ __forceinline__ void tile_mma_ready(const float *tile, const u32x4 (&
 template <int R>
 constexpr int BF_TILE_BYTES = Geom<R>::W_FLOATS * 4;
 
+// ------------------------------------------------------------------------------ screening policies of the bf16 tile loops
+// What happens to the 16 finished scores a lane holds for one tile (rows 8 g + 4 h + e of the tile, register 4 g + e) is a
+// policy object handed to the loops below:
+//   scr.template tile<PRE>(sc, tile_id, tail, label, h)
+//     sc    the scores; PRE != 0: the MFMA that wrote them is right in front (wait states are the policy's business: the
+//           compiler pads hazards only for instructions it knows, not for inline asm)
+//     tail  the tile's tail: 32 accumulator-init values, 32 class ids
+// TopKeys   the best two keys with their tiles and the third best key (4 VALU per score): finish_keys and its relatives
+// GroupKeys the same over GROUPS OF FOUR ROWS (the lane's rows 8 g + 4 h .. + 3 of a tile are four consecutive prototypes):
+//           1.5 VALU per score; finish_groups re-measures all four rows of the best group (and of the runner-up where close)
+// HitKeys   the finishing pass over samples the first pass could not settle: every row whose score lies within the margin
+//           of the running minimum is re-measured exactly on the spot (finish pass of the kernels, FINISH)
+template <bool MATCHED>
+struct TopKeys {
+    Keys2 ku;
+    KeysM km;
+    template <int PRE>
+    __device__ __forceinline__ void tile(f32x16 &sc, uint32_t tile_id, const float *tail, uint32_t label, int h)
+    {
+        if constexpr (!MATCHED) {
+            const Keys2 ou = ku;
+            screen16<PRE>(sc, ku);
+            settle_tiles(ku, ou, tile_id);
+        } else {
+            const KeysM om = km;
+            if constexpr (PRE != 0) settle_mfma(sc);
+            const uint32_t *tcls = (const uint32_t *)tail + 32 + 4 * h;
+            static_for<0, 16>([&](auto oo) {
+                constexpr int o = decltype(oo)::value;
+                const uint32_t key = pack_key(sc[o], o);
+                const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;          // helpers.rs:113 / :122
+                offer_m(km, match ? key : KEY_NONE, match ? KEY_NONE : key);
+            });
+            settle_tiles_m(km, om, tile_id);
+        }
+    }
+};
+
+// Keys of GROUPS: the minimum of a group's four scores with the group number g in the position bits.  A key stands for the
+// rows tile * 32 + 8 g + 4 h .. + 3 (h: the lane half that offered it).  Everything around the keys -- best two with
+// their tiles, third best as the witness -- is TopKeys'.  Why the guarantee survives: every row's key is at least its
+// group's, so when the third best GROUP key lies more than the margin above the best one, no row outside the best two
+// groups can be the reference's winner; all rows of those two groups are re-measured exactly (finish_groups).
+#define VQ_GROUP2_TEXT(A, B, PA, PB)                          \
+    "v_min3_f32 %[t0], %[s" #A "0], %[s" #A "1], %[s" #A "2]\n\t" \
+    "v_min3_f32 %[t1], %[s" #B "0], %[s" #B "1], %[s" #B "2]\n\t" \
+    "v_min_f32 %[t0], %[t0], %[s" #A "3]\n\t"                  \
+    "v_min_f32 %[t1], %[t1], %[s" #B "3]\n\t"                  \
+    "v_and_or_b32 %[t0], %[t0], %[m], " #PA "\n\t"             \
+    "v_and_or_b32 %[t1], %[t1], %[m], " #PB "\n\t"             \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"                \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"                \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t"                        \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t1]\n\t"                \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t1]\n\t"                \
+    "v_min_f32 %[b1], %[b1], %[t1]\n\t"
+template <int PRE_NOPS>
+__device__ __forceinline__ void screen4g(const f32x16 &sc, Keys2 &ku)
+{
+    uint32_t t0, t1;
+#define VQ_GROUP_OPERANDS                                                                                                          \
+    : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [b3] "+v"(ku.b3), [t0] "=&v"(t0), [t1] "=&v"(t1)                                          \
+    : [sa0] "v"(sc[0]), [sa1] "v"(sc[1]), [sa2] "v"(sc[2]), [sa3] "v"(sc[3]), [sb0] "v"(sc[4]), [sb1] "v"(sc[5]), [sb2] "v"(sc[6]),   \
+      [sb3] "v"(sc[7]), [sc0] "v"(sc[8]), [sc1] "v"(sc[9]), [sc2] "v"(sc[10]), [sc3] "v"(sc[11]), [sd0] "v"(sc[12]),                 \
+      [sd1] "v"(sc[13]), [sd2] "v"(sc[14]), [sd3] "v"(sc[15]), [m] "s"(0xFFFFFFF0u)
+    if constexpr (PRE_NOPS > 0)
+        asm("s_nop 15\n\ts_nop 1\n\t" VQ_GROUP2_TEXT(a, b, 0, 1) VQ_GROUP2_TEXT(c, d, 2, 3) VQ_GROUP_OPERANDS);
+    else
+        asm(VQ_GROUP2_TEXT(a, b, 0, 1) VQ_GROUP2_TEXT(c, d, 2, 3) VQ_GROUP_OPERANDS);
+#undef VQ_GROUP_OPERANDS
+}
+// minimum of a group's four scores (plain floats: nothing here is a NaN pattern, see PAD_SCORE)
+__device__ __forceinline__ float group_min(float s0, float s1, float s2, float s3)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3\n\tv_min_f32 %0, %0, %4" : "=&v"(r) : "v"(s0), "v"(s1), "v"(s2), "v"(s3));
+    return r;
+}
+
+template <bool MATCHED>
+struct GroupKeys {
+    Keys2 ku;
+    KeysM km;
+    template <int PRE>
+    __device__ __forceinline__ void tile(f32x16 &sc, uint32_t tile_id, const float *tail, uint32_t label, int h)
+    {
+        if constexpr (!MATCHED) {
+            const Keys2 ou = ku;
+            screen4g<PRE>(sc, ku);
+            settle_tiles(ku, ou, tile_id);
+        } else {
+            const KeysM om = km;
+            if constexpr (PRE != 0) settle_mfma(sc);
+            const uint32_t *tcls = (const uint32_t *)tail + 32 + 4 * h;
+            static_for<0, 4>([&](auto gg) {
+                constexpr int g = decltype(gg)::value;
+                const u32x4 cg = *(const u32x4 *)(tcls + 8 * g);
+                // rows on the wrong side of the label score PAD_SCORE (not +INF: its pattern with position bits is a NaN)
+                const bool m0 = cg[0] == label, m1 = cg[1] == label, m2 = cg[2] == label, m3 = cg[3] == label;   // helpers.rs:113 / :122
+                const float v0 = sc[4 * g + 0], v1 = sc[4 * g + 1], v2 = sc[4 * g + 2], v3 = sc[4 * g + 3];
+                const uint32_t kp = pack_key(group_min(m0 ? v0 : PAD_SCORE, m1 ? v1 : PAD_SCORE, m2 ? v2 : PAD_SCORE, m3 ? v3 : PAD_SCORE), g);
+                const uint32_t kn = pack_key(group_min(m0 ? PAD_SCORE : v0, m1 ? PAD_SCORE : v1, m2 ? PAD_SCORE : v2, m3 ? PAD_SCORE : v3), g);
+                offer_m(km, kp, kn);
+            });
+            settle_tiles_m(km, om, tile_id);
+        }
+    }
+};
+// first row of the group a GroupKeys key stands for
+__device__ __forceinline__ uint32_t group_row(uint32_t key, uint32_t tile, int h) { return tile * 32u + ((key & 3u) << 3) + 4u * (uint32_t)h; }
+
 // One tile of READY pieces into `acc` while the finished scores of the tile before (`prev`) are screened: half_step
 // for the bf16 cores.  Nothing is split here, so the tile is three MFMAs per step against two LDS reads; the screening
 // of the previous tile (one asm block) goes out behind the first step and runs while the partner wave owns the pipe.
 // On entry:  acc = accumulator-init column of the tile, (ph, pl) = this lane's pieces of its step 0,
 //            prev = finished scores of tile number tprev_id (class ids in tail_prev).
 // On exit:   acc = scores of the tile, prev = init column of the next tile (tail_next), (ph, pl) = its step-0 pieces.
-template <int R, bool MATCHED>
+template <int R, class SCR>
 __device__ __forceinline__ void pieces_step(const char *ptile, const char *pnext, const float *tail_next, const float *tail_prev,
                                             uint32_t tprev_id, uint32_t label, const u32x4 (&bh)[R / 16], const u32x4 (&bl)[R / 16],
-                                            f32x16 &acc, f32x16 &prev, u32x4 &ph, u32x4 &pl, int row, int h, Keys2 &ku, KeysM &km)
+                                            f32x16 &acc, f32x16 &prev, u32x4 &ph, u32x4 &pl, int row, int h, SCR &scr)
 {
     using Gm = Geom<R>;
     constexpr int NQ = R / 16, ROWB = Gm::ROW_FLOATS * 4;
     const char *rowp = ptile + row * ROWB + h * 32;
     u32x4 ch = ph, cl = pl, nh = ph, nl = pl;
     f32x16 cnext;
-    const Keys2 ou = ku;
-    const KeysM om = km;
     static_for<0, NQ>([&](auto qq) {
         constexpr int q = decltype(qq)::value;
         if constexpr (q + 1 < NQ) {
@@ -963,24 +1072,9 @@ __device__ __forceinline__ void pieces_step(const char *ptile, const char *pnext
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
-        if constexpr (q == 0) {
-            // prev's last MFMA sits three dependent MFMAs back; the wait states are kept all the same (bf16 MFMAs do
-            // not hold up the vector ALUs, and nothing pads hazards for inline asm)
-            if constexpr (!MATCHED) {
-                screen16<1>(prev, ku);
-                settle_tiles(ku, ou, tprev_id);
-            } else {
-                settle_mfma(prev);
-                const uint32_t *tcls = (const uint32_t *)tail_prev + 32 + 4 * h;
-                static_for<0, 16>([&](auto oo) {
-                    constexpr int o = decltype(oo)::value;
-                    const uint32_t key = pack_key(prev[o], o);
-                    const bool match = tcls[8 * (o >> 2) + (o & 3)] == label;          // helpers.rs:113 / :122
-                    offer_m(km, match ? key : KEY_NONE, match ? KEY_NONE : key);
-                });
-                settle_tiles_m(km, om, tprev_id);
-            }
-        }
+        // prev's last MFMA sits three dependent MFMAs back; the wait states are kept all the same (bf16 MFMAs do not hold
+        // up the vector ALUs, and nothing pads hazards for inline asm)
+        if constexpr (q == 0) scr.template tile<1>(prev, tprev_id, tail_prev, label, h);
         if constexpr (q == NQ / 2) {                   // NQ == 1: q == 0
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -996,9 +1090,9 @@ __device__ __forceinline__ void pieces_step(const char *ptile, const char *pnext
 
 // The search over `ntiles` tiles whose pieces are ready in LDS: tile t's pieces at pbase + t * pstride (layout:
 // BF_TILE_BYTES), its tail (init column, class ids) at tails + t * TILE_FLOATS.  Two accumulators, as search_tiles.
-template <int R, bool MATCHED>
+template <int R, class SCR>
 __device__ __forceinline__ void search_pieces(const char *pbase, uint32_t pstride, const float *tails, uint32_t ntiles, uint32_t label,
-                                              const u32x4 (&bh)[R / 16], const u32x4 (&bl)[R / 16], int s_col, int h, Keys2 &ku, KeysM &km)
+                                              const u32x4 (&bh)[R / 16], const u32x4 (&bl)[R / 16], int s_col, int h, SCR &scr)
 {
     using Gm = Geom<R>;
     constexpr int ROWB = Gm::ROW_FLOATS * 4;
@@ -1017,32 +1111,30 @@ __device__ __forceinline__ void search_pieces(const char *pbase, uint32_t pstrid
         const char *p0 = pbase + (size_t)t * pstride, *p1 = p0 + pstride, *pn = t + 2 < ntiles ? p1 + pstride : pbase;
         const float *tl0 = tails + (size_t)t * Gm::TILE_FLOATS, *tl1 = tl0 + Gm::TILE_FLOATS;
         const float *tln = t + 2 < ntiles ? tl1 + Gm::TILE_FLOATS : tails;
-        pieces_step<R, MATCHED>(p0, p1, tl1, tail_prev, tid, label, bh, bl, acc0, acc1, ph, pl, s_col, h, ku, km);
-        pieces_step<R, MATCHED>(p1, pn, tln, tl0, t, label, bh, bl, acc1, acc0, ph, pl, s_col, h, ku, km);
+        pieces_step<R>(p0, p1, tl1, tail_prev, tid, label, bh, bl, acc0, acc1, ph, pl, s_col, h, scr);
+        pieces_step<R>(p1, pn, tln, tl0, t, label, bh, bl, acc1, acc0, ph, pl, s_col, h, scr);
         tail_prev = tl1;
         tid = t + 1;
     }
     if (t < ntiles) {                                                 // odd count: acc0 holds the last tile's init column
         const float *tl = tails + (size_t)t * Gm::TILE_FLOATS;
-        pieces_step<R, MATCHED>(pbase + (size_t)t * pstride, pbase, tails, tail_prev, tid, label, bh, bl, acc0, acc1, ph, pl, s_col, h, ku, km);
-        settle_mfma(acc0);
-        last_screen<R, MATCHED>(acc0, tl - Gm::W_FLOATS, t, label, h, ku, km);
+        pieces_step<R>(pbase + (size_t)t * pstride, pbase, tails, tail_prev, tid, label, bh, bl, acc0, acc1, ph, pl, s_col, h, scr);
+        scr.template tile<1>(acc0, t, tl, label, h);
     } else if (ntiles != 0) {
-        settle_mfma(acc1);
-        last_screen<R, MATCHED>(acc1, tail_prev - Gm::W_FLOATS, tid, label, h, ku, km);
+        scr.template tile<1>(acc1, tid, tail_prev, label, h);
     }
 }
 
-// search_tiles with the products on the bf16 matrix cores; same keys, same contract.  The first nbf tiles have their
-// pieces ready in LDS at bfimg (search_pieces), the others are split on the fly.
-template <int R, bool MATCHED>
+// search_tiles with the products on the bf16 matrix cores; same contract, the screening a policy (above).  The first nbf
+// tiles have their pieces ready in LDS at bfimg (search_pieces), the others are split on the fly.
+template <int R, class SCR>
 __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntiles, uint32_t label, const u32x4 (&bh)[R / 16],
-                                                const u32x4 (&bl)[R / 16], int s_col, int h, Keys2 &ku, KeysM &km,
+                                                const u32x4 (&bl)[R / 16], int s_col, int h, SCR &scr,
                                                 const char *bfimg = nullptr, uint32_t nbf = 0)
 {
     using Gm = Geom<R>;
     constexpr int NQ = R / 16;
-    if (nbf != 0) search_pieces<R, MATCHED>(bfimg, (uint32_t)BF_TILE_BYTES<R>, img + Gm::W_FLOATS, nbf, label, bh, bl, s_col, h, ku, km);
+    if (nbf != 0) search_pieces<R>(bfimg, (uint32_t)BF_TILE_BYTES<R>, img + Gm::W_FLOATS, nbf, label, bh, bl, s_col, h, scr);
     uint32_t t = nbf;
     for (; t < ntiles; ++t) {
         const float *tile = img + (size_t)t * Gm::TILE_FLOATS;
@@ -1062,9 +1154,8 @@ __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntile
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
         });
-        // the wait states between the last MFMA and the first read of its result, tied to the accumulator so that they stay there
-        settle_mfma(acc);
-        last_screen<R, MATCHED>(acc, tile, t, label, h, ku, km);
+        // (the wait states between the last MFMA and the first read of its result are the policy's: PRE = 1)
+        scr.template tile<1>(acc, t, tile + Gm::W_FLOATS, label, h);
     }
 }
 
@@ -1119,6 +1210,69 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
         group(km.n, km.tn, km.n2, km.tn2, km.n3, wn);
     }
     if (unsafe) scan_exact_lds<R, MATCHED, ROOT>(xf, img, K, label, h, wp, wn);      // helpers.rs:55-77 in f32, rows from LDS
+}
+
+// finish_keys for GroupKeys: the lane pair agrees on the best two GROUPS of its four by (key, first row); all four rows of
+// the best group are re-measured exactly (dist(k): the pair's complete distance of row k, rooted where the model roots),
+// those of the runner-up where its key is within the margin (decided per wave, as in finish_keys); the third best group key
+// is the crowding witness.  Rows are offered in index order with strict '<' inside a group and merged by (distance, index)
+// across the two, so the lowest index wins ties (helpers.rs:70).  eligible(k): row k may win this search (k < K, and for the
+// labelled searches its class on the right side of the label); scan(): the exact in-order scan for samples that stay unsafe.
+template <bool MATCHED, class Dist, class Eligible, class Scan>
+__device__ __forceinline__ void finish_groups(int h, bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn,
+                                              Dist &&dist, Eligible &&eligible, Scan &&scan, unsigned long long *dbg = nullptr)
+{
+    const bool skip = unsafe;
+    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w, bool positive) {
+        // merge_pair with the groups' first rows in place of the rows
+        const uint32_t k1 = group_row(b1, t1, h), k2 = group_row(b2, t2, h);
+        const uint32_t pb1 = xor32(b1), pb2 = xor32(b2), pk1 = xor32(k1), pk2 = xor32(k2);
+        uint32_t f, fi, sd, si;
+        if (keyless(pb1, pk1, b1, k1)) {
+            f = pb1; fi = pk1;
+            if (keyless(b1, k1, pb2, pk2)) { sd = b1; si = k1; } else { sd = pb2; si = pk2; }
+        } else {
+            f = b1; fi = k1;
+            if (keyless(pb1, pk1, b2, k2)) { sd = pb1; si = pk1; } else { sd = b2; si = k2; }
+        }
+        const float third = pair_third(b1, b2, b3);
+        const bool have = key_valid(f) && !skip;
+        const float fk = __builtin_bit_cast(float, f);
+        auto measure4 = [&](uint32_t base, Best1 &best) {           // rows base .. base + 3, index order
+#pragma unroll
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t k = base + e;
+                if (eligible(k, positive)) best.offer(dist(k), k);
+            }
+        };
+        if (have) measure4(fi, w);
+        const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - fk > margin);
+        if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
+            if (have && key_valid(sd)) {
+                Best1 w2;
+                measure4(si, w2);
+                if (lexless(w2.d, w2.i, w.d, w.i)) w = w2;
+            }
+        }
+        if (dbg) {
+            if (__builtin_amdgcn_ballot_w64(close) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(dbg + 2, 1ull);
+            if (have && h == 0 && !(third - fk > margin)) atomicAdd(dbg + (positive ? 3 : 4), 1ull);
+            if (have && h == 0 && !(w.d < INFINITY)) atomicAdd(dbg + 5, 1ull);
+        }
+        if (have) unsafe |= !(third - fk > margin) || !(w.d < INFINITY);
+        return have;
+    };
+    if (!MATCHED) {
+        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp, true)) unsafe = true;
+    } else {
+        group(km.p, km.tp, km.p2, km.tp2, km.p3, wp, true);
+        group(km.n, km.tn, km.n2, km.tn2, km.n3, wn, false);
+    }
+    if (dbg) {
+        if (__builtin_amdgcn_ballot_w64(unsafe) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(dbg, 1ull);
+        if (unsafe && h == 0) atomicAdd(dbg + 1, 1ull);
+    }
+    if (unsafe) scan();
 }
 
 // ------------------------------------------------------------------------------ the same with the exact rows in global memory
