@@ -6,7 +6,7 @@ CSRC     := vq_amd/csrc
 # atomic optimizer off: it turns a one-lane returning atomic into atomic + immediate readfirstlane, i.e. a
 # wait for the atomic's round trip right where it is issued (k_resident_pipe claims its batches ahead of time)
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -mllvm -amdgpu-atomic-optimizer-strategy=None -Wall -Wextra -Wno-unused-parameter -Iinclude
-OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_engine.o $(CSRC)/kernels_resident.o $(CSRC)/kernels_omega.o $(CSRC)/kernels_local.o $(CSRC)/kernels_long.o $(CSRC)/kernels_direct.o \
+OBJS     := $(CSRC)/api.o $(CSRC)/kernels_scalar.o $(CSRC)/kernels_engine.o $(CSRC)/kernels_resident.o $(CSRC)/kernels_omega.o $(CSRC)/kernels_local.o $(CSRC)/kernels_long.o $(CSRC)/kernels_direct.o $(CSRC)/kernels_glvq.o \
             $(CSRC)/kernels_project.o $(CSRC)/engine_host.o $(CSRC)/synth.o
 HDRS     := $(CSRC)/vq_common.h $(CSRC)/engine.h $(CSRC)/mfma_device.h $(CSRC)/mfma_host.h $(CSRC)/mfma_images.h include/vqhip.h
 LIB      := vq_amd/libvqhip.so
@@ -25,9 +25,9 @@ $(LIBA): $(OBJS)
 	rm -f $@ && ar rcs $@ $(OBJS)
 
 # the C++ mirror's tests linked against the ARCHIVE with plain g++, the way a Rust build would link it:
-# the archive + the HIP runtime + RCCL (vqhip_multi_assign_device) + the C++ runtime, nothing else
+# the archive + the HIP runtime + the C++ runtime, nothing else (RCCL is bound by dlopen at first use)
 $(MODELS_TEST_STATIC): tests/cpp/test_models.cpp include/vq_models.hpp include/vqhip.h $(LIBA)
-	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ $(LIBA) -L$(ROCM_LIB) -lamdhip64 -lrccl -lpthread -Wl,-rpath,$(ROCM_LIB)
+	g++ -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ $(LIBA) -L$(ROCM_LIB) -lamdhip64 -ldl -lpthread -Wl,-rpath,$(ROCM_LIB)
 
 tools/hbm_stream: tools/hbm_stream.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) $< -o $@
@@ -49,7 +49,7 @@ tests/cpp/test_host_asan: tests/cpp/test_host_asan.cpp $(CSRC)/engine_host.hip $
 	    -Iinclude -I$(CSRC) -DVQHIP_HOST_TEST $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -L$(ROCM_LIB) -lrccl
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $(OBJS) -ldl
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

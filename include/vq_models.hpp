@@ -222,6 +222,10 @@ public:
     // This is an EVALUATION with the prototypes held fixed (e.g. at the start of an epoch: cost, training error, the
     // would-be update directions).  It is not `fit`: the reference updates its prototypes after every single sample
     // (glvq.rs:204-205), which a batched call cannot reproduce and does not claim to.
+    // One departure, unreachable after check_fit_constraints (every label has a prototype, glvq.rs:63-92): for a sample whose
+    // class has NO prototype (or whose class owns all of them) the reference's matched search returns index 0
+    // (helpers.rs:98) and fit goes on to measure prototype 0 (glvq.rs:177-184); here such a sample reports index 0 with
+    // distance +INF and is left out of cost, error count and gradient.
     struct Evaluation {
         std::vector<uint32_t> j_plus, j_minus;
         std::vector<double> d_plus, d_minus, mu, g_plus, g_minus;
@@ -259,6 +263,39 @@ public:
             e.misclassified += d2 < d1;
         }
         return e;
+    }
+
+    // The batch form of the two GLVQ update terms (vqhip_glvq_batch_gradient, include/vqhip.h): dW[k] = sum over the samples
+    // of glvq.rs:193-194 for the prototypes they would move, with the prototypes held fixed.  NOT the reference's `fit`
+    // (per-sample updates, glvq.rs:204-205): a full-batch step W <- W - lr * dW is a different algorithm.  Euclidean models.
+    struct BatchGradient {
+        std::vector<Vector> dW;                        // K rows of D values
+        double cost = 0.0;
+        size_t used = 0;                               // samples that have both prototypes and d+ + d- > 0
+    };
+    BatchGradient batch_gradient(const Data &data, const std::vector<std::string> &labels)
+    {
+        check_predict_constraints(data);
+        rust_assert(data.size() == labels.size(), "The data vector does not match the label vector in length.");   // glvq.rs:70
+        upload();
+        const auto table = name_table();
+        const size_t N = data.size(), D = dim(), K = prototypes_.size();
+        std::vector<uint32_t> y(N);
+        std::vector<float> X(N * D), G(K * D);
+        for (size_t i = 0; i < N; ++i) {
+            rust_assert(data[i].size() == D, "assertion failed: vec1.len() == vec2.len()");
+            for (size_t d = 0; d < D; ++d) X[i * D + d] = (float)data[i][d];
+            const auto it = table.find(labels[i]);
+            y[i] = it == table.end() ? 0xFFFFFFFFu : it->second;
+        }
+        BatchGradient g;
+        uint64_t used = 0;
+        dev_->check(vqhip_glvq_batch_gradient(dev_->get(), X.data(), y.data(), N, G.data(), &g.cost, &used));
+        g.used = (size_t)used;
+        g.dW.assign(K, Vector(D));
+        for (size_t k = 0; k < K; ++k)
+            for (size_t d = 0; d < D; ++d) g.dW[k][d] = G[k * D + d];
+        return g;
     }
 
 protected:

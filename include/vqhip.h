@@ -155,6 +155,25 @@ int vqhip_assign_matched_device(vqhip_ctx *ctx, const float *dX, const uint32_t 
 int vqhip_assign_matched_rows_f64(vqhip_ctx *ctx, const double *const *rows, const uint32_t *y, uint64_t N, uint32_t D,
                                   uint32_t *jpos, float *dpos, uint32_t *jneg, float *dneg);
 
+/* ---- batched GLVQ gradient (second half) -- NOT the reference's algorithm ------------------
+ * The reference's GLVQ::fit (src/glvq/glvq.rs:163-206) moves the two nearest prototypes after every single sample, so
+ * sample i + 1 is measured against what sample i left behind; that loop stays on the host.  This call is the BATCH form
+ * of its two update terms with the prototypes held fixed (full-batch / mini-batch GLVQ: a different algorithm whose
+ * iterates differ from the reference's):
+ *     dW[k] = sum over samples whose nearest same-class prototype is k of      -4 d- / (d+ + d-)^2 (x - w_k)   (glvq.rs:193)
+ *           + sum over samples whose nearest other-class prototype is k of     +4 d+ / (d+ + d-)^2 (x - w_k)   (glvq.rs:194)
+ * i.e. a caller's step is W <- W - lr * dW (glvq.rs:200-201 summed).  One matched search (vqhip_assign_matched) plus one
+ * HBM-bound scatter-add pass over the rows on the device.  Euclidean models with labels only (VQHIP_ERR_UNSUPPORTED with an
+ * Omega).  Samples with no prototype of / outside their class, or with d+ + d- = 0, are left out (the reference would
+ * divide by zero).  cost (nullable): sum of (d+ - d-) / (d+ + d-) over the samples that count; used (nullable): how many
+ * did.  dW: K x D, overwritten.  Sums are f32 and their order is not fixed: results agree with an f64 evaluation to
+ * rounding (tests: 1e-4 of the largest entry), not bit for bit. */
+int vqhip_glvq_batch_gradient(vqhip_ctx *ctx, const float *X, const uint32_t *y, uint64_t N, float *dW, double *cost, uint64_t *used);
+/* Device-resident form, enqueued on `stream`: ddW K x D floats on the device; dcost (nullable): 16 bytes on the device,
+ * {double cost, uint64 used}, zeroed and filled by the call. */
+int vqhip_glvq_batch_gradient_device(vqhip_ctx *ctx, const float *dX, const uint32_t *dy, uint64_t N, float *ddW, double *dcost,
+                                     void *stream);
+
 /* ---- several GPUs of one node behind one handle (SURVEY.md section 8 rows b / e) ----------------------------------
  * For a single-process caller (the Rust crate's `predict`, src/glvq/glvq.rs:217-235, whose samples are independent,
  * :224-232): one context per listed device, the model replicated on each, the samples of a call cut into contiguous
@@ -178,6 +197,9 @@ int vqhip_multi_assign_rows_f64(vqhip_multi *m, const double *const *rows, uint6
                                 float *dist_out);
 int vqhip_multi_assign_matched(vqhip_multi *m, const float *X, const uint32_t *y, uint64_t N, uint32_t *jpos,
                                float *dpos, uint32_t *jneg, float *dneg);
+/* vqhip_glvq_batch_gradient over the handle's devices: every device the gradient of its shard, summed on the host */
+int vqhip_multi_glvq_batch_gradient(vqhip_multi *m, const float *X, const uint32_t *y, uint64_t N, float *dW, double *cost,
+                                    uint64_t *used);
 
 /* The same search for shards that LIVE on the GPUs, with the RCCL exchange of the results (north star: "RCCL over xGMI is
  * used only to gather winner indices and distances"; the samples of `predict` are independent, src/glvq/glvq.rs:224-232).
@@ -187,7 +209,9 @@ int vqhip_multi_assign_matched(vqhip_multi *m, const float *X, const uint32_t *y
  * grouped ncclAllGather per array (equal shards; unequal ones: one ncclBroadcast per shard, grouped) over a
  * single-process communicator clique (ncclCommInitAll) held by the handle -- so every device ends up with the winners
  * of ALL samples.  ddist_all may be NULL.  Returns after all streams have drained.  A device listed twice in the handle:
- * VQHIP_ERR_UNSUPPORTED (one rank per GPU).  Measured on one GPU only so far (a clique of one rank); the 8-GPU exchange
+ * VQHIP_ERR_UNSUPPORTED (one rank per GPU).  librccl.so.1 is bound at the first call (dlopen), so that a process which
+ * already maps a copy -- PyTorch ships its own -- keeps exactly that one, and callers that never gather need no RCCL;
+ * VQHIP_ERR_UNSUPPORTED when it cannot be found.  Measured on one GPU only so far (a clique of one rank); the 8-GPU exchange
  * is 8 bytes per sample against >= 520 bytes read. */
 int vqhip_multi_assign_device(vqhip_multi *m, const float *const *dX, const uint64_t *n_rows, uint32_t *const *didx_all,
                               float *const *ddist_all);

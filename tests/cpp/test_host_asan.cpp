@@ -17,6 +17,7 @@ LaunchFn streamed_launcher(int, int R1, int, int *spb) { *spb = 128; return pow2
 LaunchFn resident_launcher(int R, int *spb) { *spb = 64; return pow2_in(R, 16, 128) ? &no_device : nullptr; }
 LaunchFn resident_pipe_launcher(int R, bool) { return pow2_in(R, 16, 256) ? &no_device : nullptr; }
 LaunchFn resident_cut_launcher(int R) { return pow2_in(R, 16, 256) ? &no_device : nullptr; }
+LaunchFn resident_finish_launcher(int R) { return pow2_in(R, 16, 128) ? &no_device : nullptr; }
 LaunchFn resident_staged_launcher(int R, size_t *bytes) { *bytes = 8 * 16896; return pow2_in(R, 32, 128) ? &no_device : nullptr; }
 LaunchFn omega_pipe_launcher(int R) { return pow2_in(R, 32, 128) ? &no_device : nullptr; }
 LaunchFn lowrank_launcher(int R1) { return pow2_in(R1, 32, 256) ? &no_device : nullptr; }

@@ -197,6 +197,24 @@ TEST(glvq_evaluate_matched_search_of_a_whole_set)                          // sr
     const auto l = local.evaluate(TOY, {"C0", "C0", "C0", "C1", "C1", "C1"});
     CHECK(std::fabs(l.d_plus[0] - 0.5) < 1e-6 && std::fabs(l.d_minus[0] - 90.5) < 1e-4 && l.misclassified == 0);
 }
+TEST(glvq_batch_gradient_of_the_toy_set)                                   // glvq.rs:186-194 summed with the prototypes held fixed
+{
+    GLVQ model = GLVQ::from_fitted(lvq_prototypes());                       // C0 = (5,3), C1 = (-5,11)
+    const Names labels = {"C0", "C0", "C1", "C1", "C1", "nope"};
+    const auto e = model.evaluate(TOY, labels);
+    const auto g = model.batch_gradient(TOY, labels);
+    CHECK(g.used == 5 && std::fabs(g.cost - e.cost) < 1e-5);                // "nope" has no prototype: left out
+    // the same sums in f64 from the evaluation's own factors
+    const double W[2][2] = {{5.0, 3.0}, {-5.0, 11.0}};
+    double want[2][2] = {{0, 0}, {0, 0}};
+    for (size_t i = 0; i < 5; ++i)
+        for (int d = 0; d < 2; ++d) {
+            want[e.j_plus[i]][d] += -e.g_plus[i] * (TOY[i][d] - W[e.j_plus[i]][d]);        // glvq.rs:193
+            want[e.j_minus[i]][d] += e.g_minus[i] * (TOY[i][d] - W[e.j_minus[i]][d]);      // glvq.rs:194
+        }
+    for (int k = 0; k < 2; ++k) CHECK(vec_all_close(g.dW[k], {want[k][0], want[k][1]}, 1e-4));
+    should_panic("The data vector does not match the label vector in length.", [&] { model.batch_gradient(TOY, {"C0"}); });
+}
 TEST(ties_go_to_the_first_prototype)                                       // src/helpers.rs:70
 {
     GLVQ model = GLVQ::from_fitted({{{1.0, 1.0}, "first"}, {{1.0, 1.0}, "second"}, {{9.0, 9.0}, "third"}});

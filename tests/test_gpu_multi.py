@@ -151,3 +151,100 @@ def test_misaligned_device_pointers_are_refused():
         assert rc == -1 and b"aligned" in ctx._L.vqhip_last_error(ctx._h)
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------ batched GLVQ gradient (second half)
+
+def _glvq_reference(X, y, W, cls):
+    """f64: the sums of src/glvq/glvq.rs:193-194 over all samples with the prototypes held fixed, from the oracle's matched
+    searches (the reference itself updates after every sample: this is the batch form the ABI documents)."""
+    jp, dp, _ = oracle.assign(X, W, proto_cls=cls, labels=y, matching=True, threads=8)
+    jn, dn, _ = oracle.assign(X, W, proto_cls=cls, labels=y, matching=False, threads=8)
+    dp, dn = np.asarray(dp, dtype=np.float64), np.asarray(dn, dtype=np.float64)
+    s = dp + dn
+    ok = np.isfinite(s) & (s > 0)
+    X64, W64 = X.astype(np.float64), W.astype(np.float64)
+    G = np.zeros_like(W64)
+    cp = np.where(ok, -4.0 * dn / np.where(ok, s * s, 1.0), 0.0)
+    cn = np.where(ok, 4.0 * dp / np.where(ok, s * s, 1.0), 0.0)
+    np.add.at(G, jp[ok], cp[ok, None] * (X64[ok] - W64[jp[ok]]))
+    np.add.at(G, jn[ok], cn[ok, None] * (X64[ok] - W64[jn[ok]]))
+    cost = float(((dp[ok] - dn[ok]) / s[ok]).sum())
+    return G, cost, int(ok.sum())
+
+
+@pytest.mark.parametrize("shape", [(20_003, 128, 256), (5_000, 128, 600), (3_001, 4, 3), (4_000, 100, 37), (2_500, 300, 20)],
+                         ids=lambda s: "n%d_d%d_k%d" % s)
+def test_glvq_batch_gradient_against_f64_sums(shape):
+    """vqhip_glvq_batch_gradient: matched search + scatter-add on the device (LDS partials up to ~36K prototype values, global
+    atomics beyond: K = 600) against the same sums in f64 from the oracle's matched search.  f32 sums in no fixed order: 1e-4
+    of the largest entry.  One sample in eight carries a label no prototype has: left out of gradient, cost and count."""
+    import torch
+
+    N, D, K = shape
+    rng = np.random.default_rng(N + D + K)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    X = (W[rng.integers(0, K, size=N)] + 0.4 * rng.uniform(-1, 1, size=(N, D))).astype(np.float32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    y[::8] = 7                                                             # unknown class: no matching prototype
+    want, want_cost, want_used = _glvq_reference(X, y, W, cls)
+    tol = 1e-4 * np.abs(want).max()
+    ctx = Context(0)
+    try:
+        ctx.set_kernel_policy(KERNEL_AUTO)
+        ctx.set_prototypes(W)
+        with pytest.raises(VqhipError) as e:
+            ctx.glvq_batch_gradient(X, y)                                  # labels first
+        assert e.value.code == -2
+        ctx.set_labels(cls)
+        for _ in range(2):                                                 # twice: the scratch is reused, the gradient overwritten
+            G, cost, used = ctx.glvq_batch_gradient(X, y)
+            assert used == want_used
+            assert abs(cost - want_cost) <= 1e-4 * max(1.0, abs(want_cost))
+            assert np.abs(G - want).max() <= tol, float(np.abs(G - want).max() / tol)
+        Gd, tail = ctx.glvq_batch_gradient(torch.from_numpy(X).cuda(), torch.from_numpy(y.view(np.int32)).cuda())
+        torch.cuda.synchronize()
+        assert np.abs(Gd.cpu().numpy() - want).max() <= tol
+        assert tail.cpu().numpy().view(np.uint64)[1] == want_used and abs(float(tail[0]) - want_cost) <= 1e-4 * max(1.0, abs(want_cost))
+        G0, c0, u0 = ctx.glvq_batch_gradient(X[:0], y[:0])                  # no samples: a zero gradient
+        assert (G0 == 0).all() and c0 == 0.0 and u0 == 0
+        ctx.set_omega(np.eye(D, dtype=np.float32))
+        with pytest.raises(VqhipError) as e:
+            ctx.glvq_batch_gradient(X, y)                                  # Euclidean models only
+        assert e.value.code == -5
+    finally:
+        ctx.close()
+    m = MultiContext([0, 0])
+    try:
+        m.set_prototypes(W)
+        m.set_labels(cls)
+        G, cost, used = m.glvq_batch_gradient(X, y)                        # two shards, summed on the host
+        assert used == want_used and np.abs(G - want).max() <= tol
+    finally:
+        m.close()
+
+
+def test_matched_rows_f64_against_the_oracle_at_scale():
+    """What vq::GLVQ::evaluate runs on (vqhip_assign_matched_rows_f64: the reference's container in, matched search on the device),
+    12 000 samples against the oracle, with the GLVQ cost of src/glvq/glvq.rs:171-190 derived from it."""
+    rng = np.random.default_rng(190)
+    N, D, K = 12_000, 64, 96
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    cls = np.repeat(np.arange(8), 12).astype(np.uint32)                     # the reference's order: prototypes of a class together
+    X = (W[rng.integers(0, K, size=N)] + 0.5 * rng.uniform(-1, 1, size=(N, D))).astype(np.float32)
+    y = rng.integers(0, 8, size=N).astype(np.uint32)
+    rows = [np.array(r, dtype=np.float64) for r in X]
+    ctx = Context(0)
+    try:
+        ctx.set_prototypes(W)
+        ctx.set_labels(cls)
+        jp, dp, jn, dn = ctx.assign_matched_rows(rows, y)
+        for matching, j, d in ((True, jp, dp), (False, jn, dn)):
+            rep = parity.compare(j, d, *oracle.assign(X, W, proto_cls=cls, labels=y, matching=matching, threads=8))
+            assert rep.ok, str(rep)
+        _, want_cost, _ = _glvq_reference(X, y, W, cls)
+        d1, d2 = dp.astype(np.float64), dn.astype(np.float64)
+        assert abs(float(((d1 - d2) / (d1 + d2)).sum()) - want_cost) <= 1e-5 * abs(want_cost) + 1e-6
+    finally:
+        ctx.close()

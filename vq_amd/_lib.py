@@ -40,6 +40,9 @@ SIGNATURES = {
     "vqhip_assign_matched": (C.c_int, [_v, _f, _u, C.c_uint64, _u, _f, _u, _f]),
     "vqhip_assign_matched_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), _u, C.c_uint64, C.c_uint32, _u, _f, _u, _f]),
     "vqhip_assign_matched_device": (C.c_int, [_v, _v, _v, C.c_uint64, _v, _v, _v, _v, _v]),
+    "vqhip_glvq_batch_gradient": (C.c_int, [_v, _f, _u, C.c_uint64, _f, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "vqhip_glvq_batch_gradient_device": (C.c_int, [_v, _v, _v, C.c_uint64, _v, _v, _v]),
+    "vqhip_multi_glvq_batch_gradient": (C.c_int, [_v, _f, _u, C.c_uint64, _f, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "vqhip_last_kernel": (C.c_char_p, [_v]),
     "vqhip_last_ranking": (C.c_char_p, [_v]),
     "vqhip_last_projection": (C.c_char_p, [_v]),
@@ -76,10 +79,9 @@ def _share_torch_hip_runtime():
     spec = importlib.util.find_spec("torch")
     if spec is None or not spec.submodule_search_locations:
         return
-    for name in ("libamdhip64.so", "librccl.so"):        # librccl.so.1 is NEEDED by libvqhip.so as well (vqhip_multi_assign_device)
-        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
-        if os.path.exists(path):
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def lib() -> C.CDLL:

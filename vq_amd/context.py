@@ -208,6 +208,32 @@ class Context:
         self._chk(self._L.vqhip_assign_matched_rows_f64(self._h, ptrs, _up(y), N, self.D, _up(jp), _fp(dp), _up(jn), _fp(dn)))
         return jp, dp, jn, dn
 
+    def glvq_batch_gradient(self, X, y):
+        """vqhip_glvq_batch_gradient (batch form of the two GLVQ update terms, prototypes fixed: NOT the reference's per-sample
+        SGD) -> (dW K x D, cost, samples used).  numpy in; CUDA tensors in -> (dW tensor, cost_and_count tensor of 2 x 8 bytes)."""
+        if _is_torch(X):
+            import torch
+
+            self._check_torch(X)
+            N = X.shape[0]
+            if not (y.is_cuda and y.device == X.device and y.dtype == torch.int32 and y.is_contiguous() and tuple(y.shape) == (N,)):
+                raise ValueError("y must be a contiguous CUDA int32 tensor with one class id per sample")
+            dW = torch.empty((self.K, self.D), dtype=torch.float32, device=X.device)
+            tail = torch.empty(2, dtype=torch.float64, device=X.device)
+            stream = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+            self._chk(self._L.vqhip_glvq_batch_gradient_device(self._h, C.c_void_p(X.data_ptr()), C.c_void_p(y.data_ptr()), N,
+                                                               C.c_void_p(dW.data_ptr()), C.c_void_p(tail.data_ptr()), stream))
+            return dW, tail
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.uint32)
+        self._check_shape(X.shape)
+        if y.shape != (X.shape[0],):
+            raise ValueError("y must have one class id per sample")
+        dW = np.empty((self.K, self.D), dtype=np.float32)
+        cost, used = C.c_double(0.0), C.c_uint64(0)
+        self._chk(self._L.vqhip_glvq_batch_gradient(self._h, _fp(X), _up(y), X.shape[0], _fp(dW), C.byref(cost), C.byref(used)))
+        return dW, cost.value, used.value
+
     def assign_into(self, X, idx_out, dist_out=None, y=None, jneg_out=None, dneg_out=None):
         """Device path with caller-provided torch output tensors (int32 storage for indices)."""
         import torch
@@ -338,7 +364,7 @@ class MultiContext:
     def set_prototypes(self, W):
         W = np.ascontiguousarray(W, dtype=np.float32)
         self._chk(self._L.vqhip_multi_set_prototypes(self._h, _fp(W), W.shape[0], W.shape[1]))
-        self.D = W.shape[1]
+        self.K, self.D = W.shape
 
     def set_labels(self, cls):
         cls = np.ascontiguousarray(cls, dtype=np.uint32)
@@ -370,6 +396,14 @@ class MultiContext:
         idx, dist = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.float32)
         self._chk(self._L.vqhip_multi_assign_rows_f64(self._h, ptrs, N, self.D, _up(idx), _fp(dist)))
         return idx, dist
+
+    def glvq_batch_gradient(self, X, y):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.uint32)
+        dW = np.empty((self.K, self.D), dtype=np.float32)
+        cost, used = C.c_double(0.0), C.c_uint64(0)
+        self._chk(self._L.vqhip_multi_glvq_batch_gradient(self._h, _fp(X), _up(y), X.shape[0], _fp(dW), C.byref(cost), C.byref(used)))
+        return dW, cost.value, used.value
 
     def assign_device_shards(self, shards, idx_all, dist_all=None):
         """vqhip_multi_assign_device: shards[g] = CUDA float32 tensor (n_g x D) on device g of the handle; idx_all[g] /

@@ -10,6 +10,7 @@
 #include <new>
 #include <thread>
 
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include "mfma_host.h"
@@ -89,6 +90,15 @@ struct vqhip_ctx {
     hipEvent_t scratch_done = nullptr;
 
     uint32_t *noalloc_queue = nullptr;   // this GPU's copy of `scratch` (device address, set in vqhip_create)
+
+    // vqhip_glvq_batch_gradient: the matched search's four result arrays for one chunk of rows, the accumulation scratch
+    // (partials), the gradient itself and the cost / count pair; kept between calls, grown when a call needs more
+    uint32_t *gJ[2] = {nullptr, nullptr};
+    float *gD[2] = {nullptr, nullptr};
+    uint64_t g_rows = 0;
+    float *gScratch = nullptr, *gOut = nullptr;
+    size_t gScratch_cap = 0, gOut_cap = 0;
+    double *gCost = nullptr;             // {cost (double), used (u64)} on the device
 
     EngineModel *engine = nullptr;
     // A global Omega no single-pass kernel holds (more than 128 rows over rows above 256 values; more than 64 rows
@@ -469,6 +479,81 @@ int run_host(vqhip_ctx *c, const Packer &pack, const uint32_t *y, uint64_t N, ui
     return VQHIP_OK;
 }
 
+void free_gradient(vqhip_ctx *c)
+{
+    for (int j = 0; j < 2; ++j) {
+        (void)hipFree(c->gJ[j]); (void)hipFree(c->gD[j]);
+        c->gJ[j] = nullptr; c->gD[j] = nullptr;
+    }
+    (void)hipFree(c->gScratch); (void)hipFree(c->gOut); (void)hipFree(c->gCost);
+    c->gScratch = c->gOut = nullptr;
+    c->gCost = nullptr;
+    c->g_rows = 0;
+    c->gScratch_cap = c->gOut_cap = 0;
+}
+
+// Batched GLVQ gradient of device-resident samples, enqueued on `s` (include/vqhip.h): matched search per chunk of rows,
+// then the scatter-add pass of kernels_glvq.hip.  ddW: K x D on the device.  dcost: {double cost, u64 used} on the device
+// (added to), or null.
+constexpr uint64_t GRAD_CHUNK_ROWS = 8ull << 20;
+int gradient_device(vqhip_ctx *c, const float *dX, const uint32_t *dy, uint64_t N, float *ddW, bool accumulate, double *dcost, hipStream_t s)
+{
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
+    if (c->hcls.empty()) return c->fail(VQHIP_ERR_STATE, "glvq_batch_gradient needs vqhip_set_labels");
+    if (c->omega_kind != OMEGA_NONE)
+        return c->fail(VQHIP_ERR_UNSUPPORTED, "glvq_batch_gradient serves Euclidean models (GLVQ, src/glvq/glvq.rs:186-205); clear Omega first");
+    const size_t kd = (size_t)c->K * c->D;
+    if (N == 0) {
+        if (!accumulate) HIPCHK(c, hipMemsetAsync(ddW, 0, kd * sizeof(float), s));
+        return VQHIP_OK;
+    }
+    const uint64_t chunk = std::min<uint64_t>(N, GRAD_CHUNK_ROWS);
+    uint32_t nparts = 0;
+    const size_t need = glvq_gradient_scratch_floats(c->K, c->D, &nparts);
+    if (c->g_rows < chunk || c->gScratch_cap < need) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (int j = 0; j < 2; ++j) {
+            (void)hipFree(c->gJ[j]); (void)hipFree(c->gD[j]);
+            c->gJ[j] = nullptr; c->gD[j] = nullptr;
+        }
+        (void)hipFree(c->gScratch);
+        c->gScratch = nullptr;
+        c->g_rows = 0;
+        c->gScratch_cap = 0;
+        for (int j = 0; j < 2; ++j) {
+            HIPCHK(c, hipMalloc((void **)&c->gJ[j], chunk * sizeof(uint32_t)));
+            HIPCHK(c, hipMalloc((void **)&c->gD[j], chunk * sizeof(float)));
+        }
+        HIPCHK(c, hipMalloc((void **)&c->gScratch, need * sizeof(float)));
+        c->g_rows = chunk;
+        c->gScratch_cap = need;
+    }
+    int rc = scratch_acquire(c, s);
+    if (rc != VQHIP_OK) return rc;
+    for (uint64_t off = 0; off < N; off += chunk) {
+        const uint64_t n = std::min(chunk, N - off);
+        rc = run_device(c, dX + off * c->D, n, dy + off, Outputs{c->gJ[0], c->gD[0], c->gJ[1], c->gD[1]}, s);
+        if (rc != VQHIP_OK) return rc;
+        HIPCHK(c, launch_glvq_gradient(dX + off * c->D, n, c->D, c->K, c->dW, c->gJ[0], c->gD[0], c->gJ[1], c->gD[1], c->gScratch, ddW,
+                                       accumulate || off != 0, dcost, dcost ? (unsigned long long *)(dcost + 1) : nullptr, s));
+    }
+    return scratch_release(c, s);
+}
+
+int ensure_gradient_out(vqhip_ctx *c)
+{
+    const size_t kd = (size_t)c->K * c->D;
+    if (c->gOut_cap < kd) {
+        (void)hipFree(c->gOut);
+        c->gOut = nullptr;
+        c->gOut_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->gOut, kd * sizeof(float)));
+        c->gOut_cap = kd;
+    }
+    if (!c->gCost) HIPCHK(c, hipMalloc((void **)&c->gCost, 16));
+    return VQHIP_OK;
+}
+
 uint32_t project_width(const vqhip_ctx *c, int which) { return which == VQHIP_PROJECT_OMEGA ? c->M : c->D; }
 
 int check_project(vqhip_ctx *c, int which)
@@ -807,6 +892,7 @@ try {
     (void)hipFree(c->dcls);
     (void)hipFree(c->dYproj);
     (void)hipFree(c->dProj);
+    free_gradient(c);
     if (c->scratch_done) (void)hipEventDestroy(c->scratch_done);
     delete c;
     return VQHIP_OK;
@@ -1025,6 +1111,70 @@ try {
 }
 VQHIP_CATCH(c)
 
+int vqhip_glvq_batch_gradient_device(vqhip_ctx *c, const float *dX, const uint32_t *dy, uint64_t N, float *ddW, double *dcost, void *stream)
+try {
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!ddW || (N && (!dX || !dy))) return c->fail(VQHIP_ERR_INVALID, "glvq_batch_gradient_device: dX, dy or ddW is NULL");
+    if (((uintptr_t)ddW & 3) || ((uintptr_t)dcost & 7)) return c->fail(VQHIP_ERR_INVALID, "glvq_batch_gradient_device: misaligned output");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (dcost) HIPCHK(c, hipMemsetAsync(dcost, 0, 16, (hipStream_t)stream));
+    return gradient_device(c, dX, dy, N, ddW, false, dcost, (hipStream_t)stream);
+}
+VQHIP_CATCH(c)
+
+int vqhip_glvq_batch_gradient(vqhip_ctx *c, const float *X, const uint32_t *y, uint64_t N, float *dW, double *cost, uint64_t *used)
+try {
+    if (!c) return VQHIP_ERR_INVALID;
+    if (!dW || (N && (!X || !y))) return c->fail(VQHIP_ERR_INVALID, "glvq_batch_gradient: X, y or dW is NULL");
+    if (c->K == 0) return c->fail(VQHIP_ERR_STATE, "no prototypes set (vqhip_set_prototypes)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_gradient_out(c);
+    if (rc != VQHIP_OK) return rc;
+    const size_t row = (size_t)c->D * sizeof(float), kd = (size_t)c->K * c->D;
+    size_t chunk = std::max<size_t>(1024, (128ull << 20) / row);
+    chunk = (size_t)std::min<uint64_t>(chunk, std::max<uint64_t>(N, 1));
+    if ((rc = ensure_staging(c, chunk, true)) != VQHIP_OK) return rc;
+    chunk = c->st_chunk;
+    // the two pinned buffers alternate (the CPU packs chunk i + 1 while chunk i goes up and is worked); the device work of
+    // all chunks is ordered on ONE stream: they add into the same gradient
+    hipStream_t s = c->st[0].stream;
+    HIPCHK(c, hipMemsetAsync(c->gCost, 0, 16, s));
+    const Packer pack = contiguous_f32(c, X);
+    hipEvent_t done[2] = {nullptr, nullptr};
+    auto cleanup = [&]() { for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e); };
+    rc = gradient_device(c, nullptr, nullptr, 0, c->gOut, false, nullptr, s);                  // zero the gradient
+    for (uint64_t off = 0, ci = 0; off < N && rc == VQHIP_OK; off += chunk, ++ci) {
+        Staging &b = c->st[ci & 1];
+        const uint64_t n = std::min<uint64_t>(chunk, N - off);
+        if (done[ci & 1]) {
+            if (hipEventSynchronize(done[ci & 1]) != hipSuccess) { rc = c->fail(VQHIP_ERR_HIP, "glvq_batch_gradient: event"); break; }
+        } else if (hipEventCreateWithFlags(&done[ci & 1], hipEventDisableTiming) != hipSuccess) { rc = c->fail(VQHIP_ERR_HIP, "glvq_batch_gradient: event"); break; }
+        pack(b.hX, off, n);
+        std::memcpy(b.hY, y + off, n * sizeof(uint32_t));
+        hipError_t e = hipMemcpyAsync(b.dX, b.hX, n * row, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(b.dY, b.hY, n * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { rc = c->fail_hip(e, "glvq_batch_gradient: upload"); break; }
+        rc = gradient_device(c, b.dX, b.dY, n, c->gOut, true, c->gCost, s);
+        if (rc == VQHIP_OK && hipEventRecord(done[ci & 1], s) != hipSuccess) rc = c->fail(VQHIP_ERR_HIP, "glvq_batch_gradient: event");
+    }
+    if (rc == VQHIP_OK) {
+        unsigned long long tail[2] = {0, 0};
+        hipError_t e = hipMemcpyAsync(dW, c->gOut, kd * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(tail, c->gCost, 16, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = c->fail_hip(e, "glvq_batch_gradient: download");
+        if (rc == VQHIP_OK) {
+            if (cost) std::memcpy(cost, &tail[0], 8);
+            if (used) *used = tail[1];
+        }
+    } else {
+        (void)hipStreamSynchronize(s);
+    }
+    cleanup();
+    return rc;
+}
+VQHIP_CATCH(c)
+
 int vqhip_project_device(vqhip_ctx *c, const float *dX, uint64_t N, int which, float *dY, void *stream)
 try {
     if (!c) return VQHIP_ERR_INVALID;
@@ -1109,6 +1259,51 @@ struct vqhip_multi {
 
 namespace {
 thread_local std::string g_multi_error;
+
+// RCCL is bound at first use (dlopen), not at link time: only vqhip_multi_assign_device needs it, and a process that
+// already holds a copy (PyTorch ships its own librccl.so.1) must end up with that one copy -- the loader hands back the
+// library that is already mapped under the same soname.
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    std::string why;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) {
+            const char *e = dlerror();
+            r.why = std::string("librccl.so.1 not found: ") + (e ? e : "?");
+            return;
+        }
+        auto sym = [&](const char *n) {
+            void *p = dlsym(r.handle, n);
+            if (!p && r.why.empty()) r.why = std::string("librccl: symbol ") + n + " missing";
+            return p;
+        };
+        r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+    });
+    return r;
+}
+
 
 int on_exception_multi(vqhip_multi *m) noexcept
 {
@@ -1202,7 +1397,7 @@ VQHIP_CATCH_MULTI(nullptr)
 int vqhip_multi_destroy(vqhip_multi *m)
 try {
     if (!m) return VQHIP_OK;
-    for (ncclComm_t comm : m->comms) (void)ncclCommDestroy(comm);
+    for (ncclComm_t comm : m->comms) (void)rccl().CommDestroy(comm);
     for (size_t g = 0; g < m->streams.size(); ++g) {
         (void)hipSetDevice(m->ctx[g]->device);
         (void)hipStreamDestroy(m->streams[g]);
@@ -1264,6 +1459,33 @@ try {
 }
 VQHIP_CATCH_MULTI(m)
 
+int vqhip_multi_glvq_batch_gradient(vqhip_multi *m, const float *X, const uint32_t *y, uint64_t N, float *dW, double *cost, uint64_t *used)
+try {
+    if (!m) return VQHIP_ERR_INVALID;
+    if (!dW || (N && (!X || !y))) return m->fail(VQHIP_ERR_INVALID, "multi_glvq_batch_gradient: X, y or dW is NULL");
+    const size_t n = m->ctx.size();
+    const size_t kd = (size_t)m->ctx[0]->K * m->ctx[0]->D;
+    // every device: the gradient of its shard; the shards' gradients are summed on the host in shard order (K x D floats per
+    // device: nothing next to the rows that went up).  Device-resident shards would all-reduce over the handle's RCCL clique.
+    std::vector<std::vector<float>> part(n, std::vector<float>(kd));
+    std::vector<double> pc(n, 0.0);
+    std::vector<uint64_t> pu(n, 0);
+    const int rc = on_all(m, [&](vqhip_ctx *c, size_t g) {
+        const Shard sh = shard_of(N, n, g);
+        return vqhip_glvq_batch_gradient(c, X + sh.first * c->D, y + sh.first, sh.rows, part[g].data(), &pc[g], &pu[g]);
+    }, true);
+    if (rc != VQHIP_OK) return rc;
+    for (size_t e = 0; e < kd; ++e) {
+        float t = 0.0f;
+        for (size_t g = 0; g < n; ++g) t += part[g][e];
+        dW[e] = t;
+    }
+    if (cost) { *cost = 0.0; for (double v : pc) *cost += v; }
+    if (used) { *used = 0; for (uint64_t v : pu) *used += v; }
+    return VQHIP_OK;
+}
+VQHIP_CATCH_MULTI(m)
+
 // ---- device-resident shards + the RCCL gather of the results (SURVEY.md section 8 row e) ---------------------------------
 namespace {
 // streams and the communicator clique of the handle's devices (once)
@@ -1292,9 +1514,11 @@ int multi_device_setup(vqhip_multi *m)
             for (size_t k = 0; k < g; ++k)
                 if (devs[g] == devs[k])
                     return m->fail(VQHIP_ERR_UNSUPPORTED, "multi_assign_device: a device is listed twice (RCCL wants one rank per GPU); use the host-pointer calls");
+        Rccl &R = rccl();
+        if (!R.why.empty()) return m->fail(VQHIP_ERR_UNSUPPORTED, "multi_assign_device: " + R.why);
         std::vector<ncclComm_t> comms(n);
-        const ncclResult_t r = ncclCommInitAll(comms.data(), (int)n, devs.data());
-        if (r != ncclSuccess) return m->fail(VQHIP_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        const ncclResult_t r = R.CommInitAll(comms.data(), (int)n, devs.data());
+        if (r != ncclSuccess) return m->fail(VQHIP_ERR_HIP, std::string("ncclCommInitAll: ") + R.GetErrorString(r));
         m->comms = comms;
     }
     return VQHIP_OK;
@@ -1325,25 +1549,26 @@ try {
     }
     // ... and the slices are exchanged in place, behind the kernels on the same streams: one grouped all-gather per array
     // (equal shards), or one broadcast per shard (the all-gather of unequal pieces).  8 bytes per sample over xGMI.
+    Rccl &R = rccl();
     auto exchange = [&](auto *const *arrays, ncclDataType_t type) -> ncclResult_t {
-        ncclResult_t r = ncclGroupStart();
+        ncclResult_t r = R.GroupStart();
         for (size_t g = 0; g < n && r == ncclSuccess; ++g) {
             if (equal) {
-                r = ncclAllGather(arrays[g] + first[g], arrays[g], (size_t)n_rows[0], type, m->comms[g], m->streams[g]);
+                r = R.AllGather(arrays[g] + first[g], arrays[g], (size_t)n_rows[0], type, m->comms[g], m->streams[g]);
             } else {
                 for (size_t root = 0; root < n && r == ncclSuccess; ++root)
                     if (n_rows[root])
-                        r = ncclBroadcast(arrays[g] + first[root], arrays[g] + first[root], (size_t)n_rows[root], type, (int)root,
-                                          m->comms[g], m->streams[g]);
+                        r = R.Broadcast(arrays[g] + first[root], arrays[g] + first[root], (size_t)n_rows[root], type, (int)root,
+                                        m->comms[g], m->streams[g]);
             }
         }
-        const ncclResult_t e = ncclGroupEnd();
+        const ncclResult_t e = R.GroupEnd();
         return r != ncclSuccess ? r : e;
     };
     if (first[n] != 0) {
         ncclResult_t r = exchange(didx_all, ncclUint32);
         if (r == ncclSuccess && ddist_all) r = exchange(ddist_all, ncclFloat32);
-        if (r != ncclSuccess) return m->fail(VQHIP_ERR_HIP, std::string("RCCL gather: ") + ncclGetErrorString(r));
+        if (r != ncclSuccess) return m->fail(VQHIP_ERR_HIP, std::string("RCCL gather: ") + R.GetErrorString(r));
     }
     for (size_t g = 0; g < n; ++g) {
         hipError_t e = hipSetDevice(m->ctx[g]->device);

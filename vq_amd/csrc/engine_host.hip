@@ -13,6 +13,8 @@
 
 namespace vq {
 
+constexpr uint32_t CROWD_SLOTS = 4;    // finish-pass buffer sets (launches of one model in flight at once)
+
 struct EngineModel {
     int mode = MODE_EUCLID;
     uint32_t K = 0, D = 0, M = 0, R1 = 0, R2 = 0, tiles_per_proto = 0;
@@ -41,7 +43,53 @@ struct EngineModel {
     bool bf = false;                  // k_resident_pipe: screening products on the bf16 matrix cores (mscale is then that path's)
     bool pj = false;                  // Omega kernels: the projection on the bf16 matrix cores too (img1 = three bf16 pieces per value)
     BuildOptions opt;                 // what the caller allows on the bf16 matrix cores (vqhip_set_option)
+    // The finish pass over the samples the first pass marks instead of scanning for them inside the wave (crowd_mark /
+    // HitKeys, mfma_device.h): the kernel's FINISH variant, or null (such samples are then settled in their wave).  Its
+    // buffers, one set per launch in flight like the batch counters: [3 mask words per tile of 32 samples][count][ids],
+    // sized for the largest launch so far.
+    LaunchFn finish = nullptr;
+    mutable uint32_t *crowd[CROWD_SLOTS] = {};
+    mutable uint64_t crowd_rows[CROWD_SLOTS] = {};
+    mutable uint32_t next_crowd = 0;
 };
+
+// Marked samples -> a packed list of (flags | id), any order: one thread per mask triple, a block-wide prefix sum of the
+// counts, one atomic per block to claim the block's range of the list.
+__global__ void __launch_bounds__(256) k_crowd_compact(const uint32_t *mask, uint32_t ntiles, uint32_t *list, uint32_t *count)
+{
+    __shared__ uint32_t wave_total[4], block_base;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    uint32_t mp = 0u, mn = 0u, ma = 0u;
+    if (t < ntiles) {
+        mp = mask[3 * (size_t)t];
+        mn = mask[3 * (size_t)t + 1];
+        ma = mask[3 * (size_t)t + 2];
+    }
+    uint32_t any = mp | mn | ma;
+    const uint32_t c = (uint32_t)__popc(any);
+    uint32_t incl = c;                                  // inclusive scan inside the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
+        block_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = block_base + incl - c;
+    for (int w = 0; w < wave; ++w) pos += wave_total[w];
+    while (any) {
+        const uint32_t sbit = (uint32_t)__ffs((int)any) - 1u;
+        any &= any - 1u;
+        list[pos++] = (t * 32u + sbit) | ((mp >> sbit) & 1u ? CROWD_P : 0u) | ((mn >> sbit) & 1u ? CROWD_N : 0u) | ((ma >> sbit) & 1u ? CROWD_ALL : 0u);
+    }
+}
+
 
 namespace {
 
@@ -236,6 +284,7 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
         m.lds_used = (size_t)res_tiles(m.K) * Geom<R1>::TILE_BYTES + staging;
         m.search_R = R1;
         m.search_img = 1;
+        if (variant_env() == 0 && !getenv("VQHIP_NO_FINISH")) m.finish = resident_finish_launcher(R1);
     }
     return true;
 }
@@ -741,6 +790,7 @@ void engine_free(EngineModel *m)
     (void)hipFree(m->queue);
     (void)hipFree(m->mu);
     (void)hipFree(m->imgbf);
+    for (uint32_t *p : m->crowd) (void)hipFree(p);
     delete m;
 }
 
@@ -791,7 +841,52 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     a.bfimg = m->bfimg ? 1u : 0u;
     a.pj = m->pj ? 1u : 0u;
     a.cls = m->cls;
+    a.crowd_mask = nullptr;
+    a.list = nullptr;
+    a.list_count = nullptr;
+    // The finish pass: not for the caller's own counters (the no-allocation entry point: no buffers may be made here),
+    // not beyond 2^29 rows (ids and flags share a word)
+    const bool finish = m->finish && !queue && N < (1ull << 29);
+    const uint64_t ntiles32 = (N + 31) / 32;
+    uint32_t *cbuf = nullptr;
+    if (finish) {
+        const uint32_t slot = m->next_crowd++ % CROWD_SLOTS;
+        if (m->crowd_rows[slot] < N) {
+            hipError_t ce = hipDeviceSynchronize();        // (a launch that still uses the old buffer of this slot)
+            if (ce != hipSuccess) return ce;
+            (void)hipFree(m->crowd[slot]);
+            m->crowd[slot] = nullptr;
+            m->crowd_rows[slot] = 0;
+            const uint64_t rows = N + N / 4 + 1024;
+            ce = hipMalloc((void **)&m->crowd[slot], (3 * ((rows + 31) / 32) + 4 + rows) * sizeof(uint32_t));
+            if (ce != hipSuccess) return ce;
+            m->crowd_rows[slot] = rows;
+        }
+        cbuf = m->crowd[slot];
+        const hipError_t ce = hipMemsetAsync(cbuf, 0, (3 * ntiles32 + 1) * sizeof(uint32_t), s);
+        if (ce != hipSuccess) return ce;
+        a.crowd_mask = cbuf;
+    }
     hipError_t e = m->launch(a, dy != nullptr, s);
+    if (finish && e == hipSuccess) {
+        uint32_t *count = cbuf + 3 * ntiles32, *list = count + 4;      // (the buffer holds 3 words per tile + 4 + one id per row of its largest launch)
+        hipLaunchKernelGGL(k_crowd_compact, dim3((unsigned)((ntiles32 + 255) / 256)), dim3(256), 0, s, cbuf, (uint32_t)ntiles32, list, count);
+        e = hipGetLastError();
+        if (e == hipSuccess) {
+            EngineArgs f = a;
+            f.crowd_mask = nullptr;
+            f.list = list;
+            f.list_count = count;
+            f.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
+            e = m->finish(f, dy != nullptr, s);
+            if (e == hipSuccess && getenv("VQHIP_STATS")) {              // diagnostic: how many samples the first pass marked
+                (void)hipStreamSynchronize(s);
+                uint32_t marked = 0;
+                (void)hipMemcpy(&marked, count, 4, hipMemcpyDeviceToHost);
+                fprintf(stderr, "stats: %u of %llu samples marked for the finish pass\n", marked, (unsigned long long)N);
+            }
+        }
+    }
     if (a.dbg && e == hipSuccess && getenv("VQHIP_STATS")) {
         (void)hipStreamSynchronize(s);
         unsigned long long h[8];

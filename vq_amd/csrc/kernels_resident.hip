@@ -172,10 +172,29 @@ struct Staging {
 // tails; host: pieces_image) -- nothing is split in the tile loop (search_pieces), and the exact re-measurement reads
 // its one or two rows per sample from the model's plain matrix in L2 (finish_keys_g).  For models whose f32 image
 // leaves no room for the pieces beside it (config 2): the L2 reads cost the launch 6 %, the split they replace 20 %.
-template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false, bool CUT = false, bool BF = false, bool BFIMG = false>
+//
+// FINISH (with BF): the finish pass over the samples the first pass marked (crowd_mark, mfma_device.h): batches of 32 ids
+// from a.list instead of 32 consecutive rows, rows gathered by id, every row within the margin of the running minimum
+// measured exactly (HitKeys), results scattered to the samples' own slots -- for the searches their flags name.
+template <int R, bool MATCHED, bool DIAG = false, int NW = 8, bool STAGED = false, bool CUT = false, bool BF = false, bool BFIMG = false,
+          bool FINISH = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineArgs a)
 {
     static_assert(!BF || R <= 128, "the bf16 pieces of a 256-value fragment do not fit beside the fragment");
+    static_assert(!FINISH || (BF && !STAGED && !DIAG), "the finish pass ranks on the bf16 cores and gathers its rows");
+    uint32_t count = 0;                               // FINISH: entries of the list
+    if constexpr (FINISH) {
+        count = *a.list_count;
+        if (count > a.N) count = (uint32_t)a.N;       // (never more entries than rows)
+        if (count == 0) return;                        // nothing was marked: not even the image is loaded
+    }
+    const uint64_t nbatches = FINISH ? ((uint64_t)count + 31) / 32 : a.nbatches;
+    // FINISH: the batches are dealt across the workgroups first (wave w of workgroup g starts on block w * groups + g): a
+    // short list keeps one wave per CU busy instead of eight on a few CUs, and a workgroup whose first wave finds
+    // nothing returns before it loads the image
+    if constexpr (FINISH) {
+        if ((uint64_t)blockIdx.x * 2 >= nbatches) return;
+    }
     using Gm = Geom<R>;
     using St = Staging<R>;
     unsigned long long tm[4] = {0, 0, 0, 0}, tprev_ = 0;
@@ -227,8 +246,11 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
 
     // blocks of BLOCK batches per wave: the first fixed, the others claimed a block ahead (BlockQueue)
     constexpr uint32_t BLOCK = 2;
-    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
-    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    static_assert(BLOCK == 2, "the early return of the finish pass above counts two batches per block");
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    const uint32_t wave_id = FINISH ? wave_u * gridDim.x + blockIdx.x : blockIdx.x * NW + wave_u;
+    BlockQueue<BLOCK> queue(a.queue, lane, wave_id, gridDim.x * NW, nbatches);
+    uint64_t block0 = (uint64_t)wave_id * BLOCK;
     queue.request();
     // Rows come in through a buffer descriptor rebased per batch (wave-uniform, so the 4 GiB offset
     // range is per batch, not per matrix): rows past N read as zeros by the hardware range check, one
@@ -242,9 +264,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     constexpr bool SINGLE = !STAGED && R > 128;
     constexpr int SETS = STAGED || SINGLE ? 1 : (int)BLOCK;
     f32x4 x[SETS][R / 8];
-    uint32_t ln[BLOCK];
+    uint32_t ln[BLOCK], sid[BLOCK];                    // labels; FINISH: list entries (flags | sample id) of the batches in flight
 #pragma unroll
-    for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = 0u;
+    for (uint32_t q = 0; q < BLOCK; ++q) ln[q] = sid[q] = 0u;
     auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {      // bytes from row bb*32 to the end, clamped
         const uint64_t first = bb * 32;
         if (first >= a.N) return 0u;
@@ -257,6 +279,18 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     auto fetch = [&](auto qq, uint64_t bb) {           // qq: label slot = position of bb in its block
         constexpr int q = decltype(qq)::value;
         constexpr int fset = SETS == 1 ? 0 : q;
+        if constexpr (FINISH) {
+            // entry of this lane pair's sample; slots past the list read entry 0 with no flags (searched, never stored)
+            const uint64_t slot = bb * 32 + (uint64_t)s_col;
+            uint32_t e = slot < count ? a.list[slot] : 0u;
+            if ((e & CROWD_ID) >= a.N) e = 0u;         // (an id that is no row: searched as row 0, never stored)
+            sid[q] = e;
+            const float *row = a.X + (size_t)(e & CROWD_ID) * a.D;
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) x[fset][j] = gather_chunk(row, (uint32_t)(2 * j + h), a.D);
+            if (MATCHED) ln[q] = a.y[e & CROWD_ID];
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rx =
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
         if constexpr (STAGED) {
@@ -287,7 +321,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     const uint32_t stores_per_batch = (a.out.idx ? 1u : 0u) + (a.out.dist ? 1u : 0u) +
                                       (MATCHED ? (a.out.jneg ? 1u : 0u) + (a.out.dneg ? 1u : 0u) : 0u);
     uint32_t stores_behind = 0u;                       // STAGED: store instructions issued after the pieces now in flight
-    while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
+    while (block0 < nbatches) {                       // the last block may end past nbatches: such a batch reads zeros, stores nothing
         const uint64_t nb0 = queue.take();             // first batch of the next block (the wait for its atomic is here)
         static_for<0, (int)BLOCK>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
@@ -296,7 +330,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             f32x4(&xf)[R / 8] = x[set];
             using f32x2 = __attribute__((ext_vector_type(2))) float;
             f32x2 ss2 = {0.0f, 0.0f};
-            if constexpr (CUT) {
+            if constexpr (CUT && !FINISH) {            // (gathered rows come in cut: gather_chunk)
 #pragma unroll
                 for (int j = 0; j < R / 8; ++j) xf[j] = mask_chunk(xf[j], (uint32_t)(2 * j + h), a.D);
             }
@@ -338,6 +372,36 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             if constexpr (STAGED) fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
             lap(1);                                    // 1: issue of the claim / of the staged variant's next pieces
 
+            if constexpr (FINISH) {
+                // the searches this sample was marked for; margin +INF: every row is measured (the exact scan)
+                const uint32_t flags = sid[q];
+                const float mall = (flags & CROWD_ALL) || unsafe ? INFINITY : margin;
+                HitKeys<R, MATCHED, true, !BFIMG> hits(xf, BFIMG ? a.plain : img, a.ldp, a.K, flags & (CROWD_P | CROWD_ALL) ? mall : -INFINITY,
+                                                      flags & (CROWD_N | CROWD_ALL) ? mall : -INFINITY);
+                {
+                    u32x4 bh[R / 16], bl[R / 16];
+                    split_fragment<R>(xf, bh, bl);
+                    if constexpr (BFIMG)
+                        search_pieces<R>((const char *)img, (uint32_t)Gm::TILE_BYTES, img + Gm::W_FLOATS, ntiles, label, bh, bl, s_col, h, hits);
+                    else
+                        search_tiles_bf<R>(img, ntiles, label, bh, bl, s_col, h, hits, bfimg, nbf);
+                }
+                asm volatile("" ::: "memory");
+                fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);   // the pieces are dead
+                hits.merge();
+                const uint32_t id = flags & CROWD_ID;
+                if (flags & (CROWD_P | CROWD_ALL)) {
+                    if (h == 0) {
+                        if (a.out.idx) a.out.idx[id] = hits.wp.i;
+                    } else if (a.out.dist) a.out.dist[id] = hits.wp.d;
+                }
+                if (MATCHED && (flags & (CROWD_N | CROWD_ALL))) {
+                    if (h == 0) {
+                        if (a.out.jneg) a.out.jneg[id] = hits.wn.i;
+                    } else if (a.out.dneg) a.out.dneg[id] = hits.wn.d;
+                }
+                return;
+            }
             TopKeys<MATCHED> scr;
             Keys2 &ku = scr.ku;
             KeysM &km = scr.km;
@@ -365,14 +429,14 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
 
             Best1 wp, wn;
             if constexpr (AHEAD)       // the next batch's rows go out behind the request for the candidate's row
-                finish_keys_ahead<R>(xf, a.plain, a.ldp, a.K, h, unsafe, margin, ku, wp, [&]() { fetch_next(); });
+                finish_keys_ahead<R>(xf, a.plain, a.ldp, a.K, h, unsafe, margin, ku, wp, [&]() { fetch_next(); }, a.crowd_mask, b, a.N);
             else if constexpr (BFIMG) {
-                finish_keys_g<R, MATCHED>(xf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+                finish_keys_g<R, MATCHED>(xf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn, a.crowd_mask, b, a.N);
                 if constexpr (LATE) {
                     asm volatile("" ::: "memory");
                     fetch_next();
                 }
-            } else finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+            } else finish_keys<R, MATCHED>(xf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn, a.crowd_mask, b, a.N);
             {   // lanes h = 0 store the index, lanes h = 1 the distance; rows past N are dropped by the range check
                 const int rec = (int)records(b, 4u);
                 const uint32_t so = (uint32_t)s_col * 4u;
@@ -518,6 +582,39 @@ hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t s
     return hipGetLastError();
 }
 }  // namespace
+
+namespace {
+// the finish pass of every pipelined variant (pipe / staged / cut): rows gathered and cut at D, bf16 ranking, the
+// image as the first pass left it (pieces only: a.bfimg, or f32 with a.nbf ready tiles behind)
+template <int R>
+hipError_t launch_resident_finish(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    const dim3 grid(256), block(512);
+    if (a.bfimg) {
+        if (matched)
+            hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, true, true, true, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, false, true, true, true, true>), grid, block, 0, st, a);
+    } else if (matched)
+        hipLaunchKernelGGL((k_resident_pipe<R, true, false, 8, false, true, true, false, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((k_resident_pipe<R, false, false, 8, false, true, true, false, true>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn resident_finish_launcher(int R)
+{
+    switch (R) {
+    case 16: return &launch_resident_finish<16>;
+    case 32: return &launch_resident_finish<32>;
+    case 64: return &launch_resident_finish<64>;
+    case 128: return &launch_resident_finish<128>;
+    default: return nullptr;
+    }
+}
 
 LaunchFn resident_launcher(int R, int *samples_per_batch)
 {

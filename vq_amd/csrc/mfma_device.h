@@ -45,6 +45,12 @@ struct EngineArgs {
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
     const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
+    // Samples the screening cannot settle (crowd_mark below).  First pass: crowd_mask = three bit planes per tile of 32
+    // samples (zeroed before the launch), or null: such samples take the exact scan inside their wave.  Finish pass
+    // (FINISH kernels): list = their ids, packed by k_crowd_compact, list_count = how many.
+    uint32_t *crowd_mask;
+    const uint32_t *list;
+    const uint32_t *list_count;
 };
 
 namespace {
@@ -399,6 +405,22 @@ __device__ __forceinline__ f32x4 mask_chunk(f32x4 v, uint32_t c, uint32_t D)
     const uint32_t first = 4u * c;
     if (first + 4u <= D) return v;
     return f32x4{first + 0u < D ? v[0] : 0.f, first + 1u < D ? v[1] : 0.f, first + 2u < D ? v[2] : 0.f, 0.f};
+}
+
+// 16 bytes of a row that is only known to be 4-byte aligned (gathered rows of the finish pass)
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4 load16(const float *p) { return *(const f32x4_a4 *)p; }
+// chunk c (16 bytes) of a gathered row of D floats through a plain pointer: nothing past the row's end is touched (the
+// row may be the last of its allocation; the buffer loads of the first pass are range-checked by the hardware instead)
+__device__ __forceinline__ f32x4 gather_chunk(const float *row, uint32_t c, uint32_t D)
+{
+    const uint32_t first = 4u * c;
+    if (first + 4u <= D) return load16(row + first);
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (first + 0u < D) v[0] = row[first + 0u];
+    if (first + 1u < D) v[1] = row[first + 1u];
+    if (first + 2u < D) v[2] = row[first + 2u];
+    return v;
 }
 
 // Centre of the model (EngineArgs::mu) -> LDS at kernel start, NF floats; the caller's barrier publishes it.
@@ -932,6 +954,70 @@ __device__ __forceinline__ void tile_mma_ready(const float *tile, const u32x4 (&
 template <int R>
 constexpr int BF_TILE_BYTES = Geom<R>::W_FLOATS * 4;
 
+// ------------------------------------------------------------------------------ samples the screening cannot settle
+// A sample whose third best key lies within the margin of its best one (or whose scores mean nothing: NaN / INF / huge
+// rows) needs every close prototype measured exactly.  Doing that inside the wave makes 63 lanes wait for one: at 4 096
+// random prototypes 0.7 % of the samples are crowded and one wave-batch in five walked all 4 096 rows on their behalf.
+// Instead the first pass MARKS them -- one bit per sample in a mask word per tile of 32 samples, no atomics -- and
+// carries on; k_crowd_compact packs the marked samples into a list and the kernel's FINISH variant works the list, 32
+// crowded samples per wave (HitKeys below).  Bit planes of tile t: mask[3 t] the unlabelled / matching search is
+// crowded, mask[3 t + 1] the non-matching search is, mask[3 t + 2] take every row (unusable scores).
+constexpr uint32_t CROWD_P = 1u << 29, CROWD_N = 1u << 30, CROWD_ALL = 1u << 31, CROWD_ID = CROWD_P - 1u;   // list entry: flags | sample
+// Wave-uniform call.  Returns true when the marks were taken (the finish pass answers for the marked samples).  Only rows
+// that exist are marked: a batch's lanes past row N (and whole batches past the last one, which the kernels run on
+// zeros) must leave no bit behind -- their tile may not even have mask words.
+__device__ __forceinline__ bool crowd_mark(uint32_t *mask, uint64_t tile32, uint64_t N, bool cp, bool cn, bool all, int h)
+{
+    if (mask == nullptr) return false;
+    const bool live = h == 0 && tile32 * 32 + (uint64_t)(threadIdx.x & 31) < N;
+    const uint32_t mp = (uint32_t)__builtin_amdgcn_ballot_w64(cp && live), mn = (uint32_t)__builtin_amdgcn_ballot_w64(cn && live);
+    const uint32_t ma = (uint32_t)__builtin_amdgcn_ballot_w64(all && live);
+    if ((mp | mn | ma) != 0u && (threadIdx.x & 63) == 0) {
+        uint32_t *w = mask + 3 * tile32;
+        if (mp) w[0] = mp;
+        if (mn) w[1] = mn;
+        if (ma) w[2] = ma;
+    }
+    return true;
+}
+
+// This lane's part of the exact distance of row k (its chunks of the row; the lane pair's two parts add up to exact_sq_*'s
+// value in exact_sq_*'s order, so a distance does not depend on which pass measured it)
+template <int R>
+__device__ __forceinline__ float exact_part_lds(const f32x4 (&xf)[R / 8], const float *img, uint32_t k, int h)
+{
+    using Gm = Geom<R>;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const float *rowp = img + (size_t)(k >> 5) * Gm::TILE_FLOATS + Gm::chunk_off((int)(k & 31u), h);
+    f32x2 p = {0.0f, 0.0f};
+    const f32x2 half = {0.5f, 0.5f};
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 v = *(const f32x4 *)(rowp + 8 * j);                          // v = -2 w
+        const f32x2 d0 = __builtin_elementwise_fma(half, f32x2{v[0], v[1]}, f32x2{xf[j][0], xf[j][1]});
+        const f32x2 d1 = __builtin_elementwise_fma(half, f32x2{v[2], v[3]}, f32x2{xf[j][2], xf[j][3]});
+        p = __builtin_elementwise_fma(d0, d0, p);
+        p = __builtin_elementwise_fma(d1, d1, p);
+    }
+    return p[0] + p[1];
+}
+template <int R>
+__device__ __forceinline__ float exact_part_g(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t k, int h)
+{
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const float *w = plain + (size_t)k * ldp + 4 * h;
+    f32x2 p = {0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 v = *(const f32x4 *)(w + 8 * j);
+        const f32x2 d0 = f32x2{xf[j][0], xf[j][1]} - f32x2{v[0], v[1]};
+        const f32x2 d1 = f32x2{xf[j][2], xf[j][3]} - f32x2{v[2], v[3]};
+        p = __builtin_elementwise_fma(d0, d0, p);
+        p = __builtin_elementwise_fma(d1, d1, p);
+    }
+    return p[0] + p[1];
+}
+
 // ------------------------------------------------------------------------------ screening policies of the bf16 tile loops
 // What happens to the 16 finished scores a lane holds for one tile (rows 8 g + 4 h + e of the tile, register 4 g + e) is a
 // policy object handed to the loops below:
@@ -1040,6 +1126,85 @@ struct GroupKeys {
         }
     }
 };
+// The finish pass: every row whose score is within the margin of the lane's RUNNING minimum is measured exactly at once
+// and offered in index order (strict '<': helpers.rs:70).  Why that is enough: a key differs from the true score by less
+// than margin / 2, so the reference's winner scores at most `margin` above the least score of all rows -- and the
+// running minimum, taken over a subset, is never below that.  Early tiles measure a few rows more than the final
+// minimum would ask for; the lane pair's two lists are merged by (distance, index) at the end.  A row is measured by
+// BOTH lanes of its pair (each holds half of the sample's chunks), so hits are worked one score register at a time with
+// the partner's row number exchanged.  margin = +INF (unusable scores) makes every row a hit: the exact scan.
+//   LDSROWS  the exact rows come from the f32 image in LDS (rows = the image), else from the plain matrix (K x ldp)
+template <int R, bool MATCHED, bool ROOT, bool LDSROWS>
+struct HitKeys {
+    const f32x4 (&xf)[R / 8];
+    const float *rows;
+    uint32_t ldp, K;
+    float margin_p, margin_n;          // -INF: the search is not this sample's problem (no hits, nothing stored)
+    float run_p = INFINITY, run_n = INFINITY;
+    Best1 wp, wn;
+    __device__ __forceinline__ HitKeys(const f32x4 (&xf_)[R / 8], const float *rows_, uint32_t ldp_, uint32_t K_, float mp, float mn)
+        : xf(xf_), rows(rows_), ldp(ldp_), K(K_), margin_p(mp), margin_n(mn) {}
+    __device__ __forceinline__ float part(uint32_t k, int h) const
+    {
+        if constexpr (LDSROWS) return exact_part_lds<R>(xf, rows, k, h);
+        else return exact_part_g<R>(xf, rows, ldp, k, h);
+    }
+    template <int PRE>
+    __device__ __forceinline__ void tile(f32x16 &sc, uint32_t tile_id, const float *tail, uint32_t label, int h)
+    {
+        if constexpr (PRE != 0) settle_mfma(sc);
+        const uint32_t *tcls = (const uint32_t *)tail + 32 + 4 * h;
+        bool match[16];
+        // running minima first (they include this tile), then the thresholds
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            match[o] = !MATCHED || tcls[8 * (o >> 2) + (o & 3)] == label;             // helpers.rs:113 / :122
+            const float v = sc[o];
+            if (match[o]) run_p = fminf(run_p, v);
+            else run_n = fminf(run_n, v);
+        }
+        const bool en_p = margin_p > -INFINITY, en_n = margin_n > -INFINITY;
+        const float thr_p = run_p + margin_p, thr_n = run_n + margin_n;
+        bool any = false;
+        bool hit[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            hit[o] = (match[o] ? en_p : en_n) && !(sc[o] > (match[o] ? thr_p : thr_n));   // NaN scores count as hits: measured, never win
+            any |= hit[o];
+        }
+        if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
+        // One step measures, for every lane, the first of ITS remaining hits of this tile (rows in index order inside a
+        // lane): as many steps as the busiest lane has hits, not one per score register -- every step is a round trip to
+        // the exact rows for the whole wave.
+        uint32_t hm = 0u;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) hm |= hit[o] ? 1u << o : 0u;
+        while (__builtin_amdgcn_ballot_w64(hm != 0u) != 0ull) {
+            const uint32_t o = hm != 0u ? (uint32_t)__builtin_ctz(hm) : 0u;
+            const uint32_t k = tile_id * 32u + 8u * (o >> 2) + 4u * (uint32_t)h + (o & 3u);
+            const uint32_t mine = hm != 0u && k < K ? k : 0xFFFFFFFFu;
+            hm &= hm - 1u;
+            const uint32_t theirs = xor32(mine);
+            const float pm = mine != 0xFFFFFFFFu ? part(mine, h) : 0.0f;
+            const float pt = theirs != 0xFFFFFFFFu ? part(theirs, h) : 0.0f;
+            const float got = xor32(pt);                                               // the partner's part of MY row
+            if (mine != 0xFFFFFFFFu) {
+                const float total = pm + got;
+                const float d = ROOT ? sqrtf(total) : total;
+                const bool mine_matches = !MATCHED || tcls[8u * (o >> 2) + (o & 3u)] == label;
+                if (mine_matches) wp.offer(d, k);
+                else wn.offer(d, k);
+            }
+        }
+    }
+    // the lane pair's answer
+    __device__ __forceinline__ void merge()
+    {
+        wp.merge_halves();
+        wn.merge_halves();
+    }
+};
+
 // first row of the group a GroupKeys key stands for
 __device__ __forceinline__ uint32_t group_row(uint32_t key, uint32_t tile, int h) { return tile * 32u + ((key & 3u) << 3) + 4u * (uint32_t)h; }
 
@@ -1171,7 +1336,8 @@ __device__ __forceinline__ void search_tiles_bf(const float *img, uint32_t ntile
 // f32 (strict '<' in index order, so the lowest index wins ties).
 template <int R, bool MATCHED, bool ROOT = true>
 __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const float *img, uint32_t K, uint32_t label, int h,
-                                            bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn)
+                                            bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn,
+                                            uint32_t *crowd_mask = nullptr, uint64_t tile32 = 0, uint64_t N = 0)
 {
     // helpers.rs:23 (rooted) vs helpers.rs:44 (squared)
     auto dist = [&](uint32_t k) {
@@ -1181,7 +1347,8 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
     // best two of the pair's four by (key, index), re-measured; the runner-up only where its key is within the margin
     // of the winner's (decided per wave: the re-measurement is 80 VALU + 16 LDS reads for every lane or for none)
     const bool skip = unsafe;                          // NaN / INF / huge rows: their keys mean nothing
-    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w) {
+    bool all = unsafe;                                 // take every row: unusable scores, or a winner that is not finite
+    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w, bool &crowded) {
         uint32_t f, fi, sd, si;
         merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
         const float third = pair_third(b1, b2, b3);
@@ -1200,16 +1367,19 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
             }
         }
         // crowded: a third key within the margin; a non-finite re-measured winner cannot be trusted either
-        if (have) unsafe |= !(third - fk > margin) || !(w.d < INFINITY);
+        crowded = have && !(third - fk > margin);
+        if (have) all |= !(w.d < INFINITY);
         return have;
     };
+    bool cp = false, cn = false;
     if (!MATCHED) {
-        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp)) unsafe = true;      // no usable key at all: the scan answers (0, +INF)
+        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp, cp)) all = true;      // no usable key at all: the scan answers (0, +INF)
     } else {
-        group(km.p, km.tp, km.p2, km.tp2, km.p3, wp);
-        group(km.n, km.tn, km.n2, km.tn2, km.n3, wn);
+        group(km.p, km.tp, km.p2, km.tp2, km.p3, wp, cp);
+        group(km.n, km.tn, km.n2, km.tn2, km.n3, wn, cn);
     }
-    if (unsafe) scan_exact_lds<R, MATCHED, ROOT>(xf, img, K, label, h, wp, wn);      // helpers.rs:55-77 in f32, rows from LDS
+    // marked for the finish pass (crowd_mark), or settled here: helpers.rs:55-77 in f32, rows from LDS
+    if (!crowd_mark(crowd_mask, tile32, N, cp, cn, all, h) && (cp || cn || all)) scan_exact_lds<R, MATCHED, ROOT>(xf, img, K, label, h, wp, wn);
 }
 
 // finish_keys for GroupKeys: the lane pair agrees on the best two GROUPS of its four by (key, first row); all four rows of
@@ -1220,9 +1390,11 @@ __device__ __forceinline__ void finish_keys(const f32x4 (&xf)[R / 8], const floa
 // labelled searches its class on the right side of the label); scan(): the exact in-order scan for samples that stay unsafe.
 template <bool MATCHED, class Dist, class Eligible, class Scan>
 __device__ __forceinline__ void finish_groups(int h, bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp, Best1 &wn,
-                                              Dist &&dist, Eligible &&eligible, Scan &&scan, unsigned long long *dbg = nullptr)
+                                              Dist &&dist, Eligible &&eligible, Scan &&scan, unsigned long long *dbg = nullptr,
+                                              uint32_t *crowd_mask = nullptr, uint64_t tile32 = 0, uint64_t N = 0)
 {
     const bool skip = unsafe;
+    bool all = unsafe, cp = false, cn = false;
     auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w, bool positive) {
         // merge_pair with the groups' first rows in place of the rows
         const uint32_t k1 = group_row(b1, t1, h), k2 = group_row(b2, t2, h);
@@ -1259,20 +1431,24 @@ __device__ __forceinline__ void finish_groups(int h, bool unsafe, float margin, 
             if (have && h == 0 && !(third - fk > margin)) atomicAdd(dbg + (positive ? 3 : 4), 1ull);
             if (have && h == 0 && !(w.d < INFINITY)) atomicAdd(dbg + 5, 1ull);
         }
-        if (have) unsafe |= !(third - fk > margin) || !(w.d < INFINITY);
+        if (have) {
+            (positive ? cp : cn) = !(third - fk > margin);
+            all |= !(w.d < INFINITY);
+        }
         return have;
     };
     if (!MATCHED) {
-        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp, true)) unsafe = true;
+        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp, true)) all = true;
     } else {
         group(km.p, km.tp, km.p2, km.tp2, km.p3, wp, true);
         group(km.n, km.tn, km.n2, km.tn2, km.n3, wn, false);
     }
+    unsafe = cp || cn || all;
     if (dbg) {
         if (__builtin_amdgcn_ballot_w64(unsafe) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(dbg, 1ull);
         if (unsafe && h == 0) atomicAdd(dbg + 1, 1ull);
     }
-    if (unsafe) scan();
+    if (!crowd_mark(crowd_mask, tile32, N, cp, cn, all, h) && unsafe) scan();
 }
 
 // ------------------------------------------------------------------------------ the same with the exact rows in global memory
@@ -1300,14 +1476,15 @@ __device__ __forceinline__ float exact_sq_g(const f32x4 (&xf)[R / 8], const floa
 template <int R, bool MATCHED, bool ROOT = true>
 __device__ __forceinline__ void finish_keys_g(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, const uint32_t *cls, uint32_t K,
                                               uint32_t label, int h, bool unsafe, float margin, const Keys2 &ku, const KeysM &km, Best1 &wp,
-                                              Best1 &wn)
+                                              Best1 &wn, uint32_t *crowd_mask = nullptr, uint64_t tile32 = 0, uint64_t N = 0)
 {
     auto dist = [&](uint32_t k) {
         const float d = exact_sq_g<R>(xf, plain, ldp, k, h);
         return ROOT ? sqrtf(d) : d;
     };
     const bool skip = unsafe;
-    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w) {
+    bool all = unsafe;
+    auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w, bool &crowded) {
         uint32_t f, fi, sd, si;
         merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
         const float third = pair_third(b1, b2, b3);
@@ -1325,16 +1502,18 @@ __device__ __forceinline__ void finish_keys_g(const f32x4 (&xf)[R / 8], const fl
                 if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
             }
         }
-        if (have) unsafe |= !(third - fk > margin) || !(w.d < INFINITY);
+        crowded = have && !(third - fk > margin);
+        if (have) all |= !(w.d < INFINITY);
         return have;
     };
+    bool cp = false, cn = false;
     if (!MATCHED) {
-        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp)) unsafe = true;
+        if (!group(ku.b1, ku.t1, ku.b2, ku.t2, ku.b3, wp, cp)) all = true;
     } else {
-        group(km.p, km.tp, km.p2, km.tp2, km.p3, wp);
-        group(km.n, km.tn, km.n2, km.tn2, km.n3, wn);
+        group(km.p, km.tp, km.p2, km.tp2, km.p3, wp, cp);
+        group(km.n, km.tn, km.n2, km.tn2, km.n3, wn, cn);
     }
-    if (unsafe) {                                       // helpers.rs:55-77 / 91-132 in f32, in index order
+    if (!crowd_mark(crowd_mask, tile32, N, cp, cn, all, h) && (cp || cn || all)) {     // helpers.rs:55-77 / 91-132 in f32, in index order
         wp = Best1();
         wn = Best1();
         for (uint32_t k = 0; k < K; ++k) {
@@ -1376,7 +1555,8 @@ __device__ __forceinline__ float rows_sq(const f32x4 (&xf)[R / 8], const f32x4 (
 // epilogue per batch with the samples requested first, 5.8k this way).  Same sums as exact_sq_g.
 template <int R, bool ROOT = true, class Between>
 __device__ __forceinline__ void finish_keys_ahead(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t K, int h, bool unsafe,
-                                                  float margin, const Keys2 &ku, Best1 &wp, Between &&between)
+                                                  float margin, const Keys2 &ku, Best1 &wp, Between &&between,
+                                                  uint32_t *crowd_mask = nullptr, uint64_t tile32 = 0, uint64_t N = 0)
 {
     const __amdgpu_buffer_rsrc_t rplain = __builtin_amdgcn_make_buffer_rsrc((void *)plain, 0, (int)(K * ldp * 4u), 0x00020000);
     auto dist = [&](uint32_t k) {
@@ -1408,8 +1588,10 @@ __device__ __forceinline__ void finish_keys_ahead(const f32x4 (&xf)[R / 8], cons
             if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
         }
     }
-    // crowded (a third key within the margin), a non-finite winner, or no usable key at all: the exact scan answers
-    if (!have || !(third - fk > margin) || !(wp.d < INFINITY)) {
+    // crowded (a third key within the margin), a non-finite winner, or no usable key at all: marked for the finish pass
+    // (crowd_mark), or the exact scan answers here
+    const bool crowded = have && !(third - fk > margin), all = !have || !(wp.d < INFINITY);
+    if (!crowd_mark(crowd_mask, tile32, N, crowded, false, all, h) && (crowded || all)) {
         wp = Best1();                                   // helpers.rs:55-77 in f32, in index order
         for (uint32_t k = 0; k < K; ++k) wp.offer(dist(k), k);
     }

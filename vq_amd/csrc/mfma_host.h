@@ -19,6 +19,7 @@ LaunchFn streamed_launcher(int mode, int R1, int R2, int *samples_per_batch);   
 LaunchFn resident_launcher(int R, int *samples_per_batch);                       // kernels_resident.hip: k_resident
 LaunchFn resident_pipe_launcher(int R, bool diag);                               // kernels_resident.hip: k_resident_pipe
 LaunchFn resident_cut_launcher(int R);                                           // k_resident_pipe for rows shorter than R
+LaunchFn resident_finish_launcher(int R);   // k_resident_pipe FINISH: the finish pass over the marked samples (bf16 ranking only)
 // k_resident_pipe with rows staged through LDS (few prototypes); staging_bytes: LDS it needs behind the image
 LaunchFn resident_staged_launcher(int R, size_t *staging_bytes);
 LaunchFn omega_pipe_launcher(int R);                                             // kernels_omega.hip: k_omega_pipe

@@ -110,6 +110,15 @@ size_t local_project_scratch_words(const LocalProjectModel *m, uint64_t n);
 hipError_t local_project_run(const LocalProjectModel *m, const float *dX, uint64_t n, const uint32_t *dwin, uint32_t *scratch,
                              float *dY, hipStream_t s);
 
+// ---------------------------------------------------------------- batched GLVQ gradient (kernels_glvq.hip)
+// scratch floats the pass needs for a K x D model; *nparts: partial sets it leaves (256: one per workgroup, LDS; 1: global atomics)
+size_t glvq_gradient_scratch_floats(uint32_t K, uint32_t D, uint32_t *nparts);
+// G (K x D, device) = (accumulate ? G : 0) + the batch gradient of the samples dX (N x D) whose matched search gave
+// (jp, dp, jn, dn); dcost / dused (device, nullable) are added to
+hipError_t launch_glvq_gradient(const float *dX, uint64_t N, uint32_t D, uint32_t K, const float *dW, const uint32_t *jp, const float *dp,
+                                const uint32_t *jn, const float *dn, float *scratch, float *dG, bool accumulate, double *dcost,
+                                unsigned long long *dused, hipStream_t s);
+
 // ---------------------------------------------------------------- synth (synth.hip)
 hipError_t launch_synth_fill(float *dout, uint64_t count, uint64_t first, uint64_t seed, uint32_t stream_id,
                              float scale, const float *dbase, uint64_t base_len, hipStream_t s);
