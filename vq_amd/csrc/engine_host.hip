@@ -277,6 +277,8 @@ bool bind_euclid(EngineModel &m, std::vector<float> &img, const std::vector<floa
     // k_engine and the pipelined resident kernels rank on the bf16 matrix cores (k_resident, padded rows, does not)
     const bool plain_diag = variant_env() == 31 || variant_env() == 32;
     if (R1 <= 128 && std::strcmp(m.name, "mfma_euclid_lds") != 0 && !plain_diag) set_bf(m, R1);
+    if (m.bf && std::strcmp(m.name, "mfma_euclid") == 0 && variant_env() == 0 && !getenv("VQHIP_NO_FINISH"))
+        m.finish = streamed_finish_launcher(MODE_EUCLID, R1, R1);
     if (m.bf && std::strncmp(m.name, "mfma_euclid_lds_", 16) == 0) {      // pipe / staged / cut: the image is resident
         size_t staging = 0;
         if (std::strcmp(m.name, "mfma_euclid_lds_staged") == 0) (void)resident_staged_launcher(R1, &staging);

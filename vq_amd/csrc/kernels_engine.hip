@@ -35,11 +35,22 @@ namespace vq {
 // GRP (with BF): the keys stand for groups of four prototypes (GroupKeys / finish_groups, mfma_device.h): 1.5 VALU per score
 // instead of 4, four exact rows per candidate in the epilogue -- for models of many tiles, where the screening is most of
 // the instruction stream and the epilogue a small part of a batch.
-template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, bool BF = false, bool GRP = false>
+// FINISH (with BF, not GRP): the finish pass over the samples the first pass marked (crowd_mark / HitKeys, mfma_device.h):
+// batches of ids from a.list, rows gathered by id, results scattered -- k_resident_pipe's FINISH for the streamed engine.
+template <int MODE, int R1, int R2, int S, bool MATCHED, int WPS, bool BF = false, bool GRP = false, bool FINISH = false>
 __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
 {
     static_assert(!BF || MODE != MODE_LOCAL, "LOCAL has no ranking stage");
     static_assert(!GRP || BF, "group keys come with the bf16 ranking");
+    static_assert(!FINISH || (BF && !GRP), "the finish pass ranks on the bf16 cores");
+    uint32_t count = 0;                               // FINISH: entries of the list
+    if constexpr (FINISH) {
+        count = *a.list_count;
+        if (count > a.N) count = (uint32_t)a.N;
+        if (count == 0) return;
+    }
+    const uint64_t nbatches = FINISH ? ((uint64_t)count + 4 * S * 32 - 1) / (4 * S * 32) : a.nbatches;
+    if (FINISH && blockIdx.x >= nbatches) return;      // (before the first barrier: the whole workgroup leaves)
     using G1 = Geom<R1>;
     using G2 = Geom<MODE == MODE_OMEGA ? R2 : R1>;
     constexpr int RS = MODE == MODE_OMEGA ? R2 : R1;                 // reduction length of the search stage
@@ -71,7 +82,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
     // check, one per-lane offset + immediates serves every chunk.  The loads are raw: nothing here waits for
     // them, so a batch can be fetched while the previous one is searched.
     f32x4 xf[S][R1 / 8];
-    uint32_t label[S];
+    uint32_t label[S], sid[S];                                        // sid: FINISH: list entries (flags | sample id)
     const uint32_t row_bytes = a.D * 4u;
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
@@ -79,6 +90,18 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint64_t first = ((bb * 4 + wave_u) * S + s) * 32;
+            if constexpr (FINISH) {
+                // entry of this lane pair's sample; slots past the list: row 0 with no flags (searched, never stored)
+                const uint64_t slot = first + (uint64_t)s_col;
+                uint32_t e = slot < count ? a.list[slot] : 0u;
+                if ((e & CROWD_ID) >= a.N) e = 0u;
+                sid[s] = e;
+                const float *row = a.X + (size_t)(e & CROWD_ID) * a.D;
+#pragma unroll
+                for (int j = 0; j < R1 / 8; ++j) xf[s][j] = gather_chunk(row, (uint32_t)(2 * j + h), a.D);
+                label[s] = MATCHED ? a.y[e & CROWD_ID] : 0u;
+                continue;
+            }
             uint32_t rec = 0u, rec_y = 0u;
             if (bb < a.nbatches && first < a.N) {
                 const uint64_t left = a.N - first;
@@ -100,7 +123,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
     // D < R1: the chunks past the row's end hold the next row's values (or range-check zeros); the weight
     // images are zero there, but 0 x INF is NaN, so they are cleared before the rows are used
     auto mask_columns = [&]() {
-        if (a.D < (uint32_t)R1) {
+        if (!FINISH && a.D < (uint32_t)R1) {           // (gathered rows come in cut: gather_chunk)
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -118,7 +141,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
 #endif
     int cur = 0;
     uint64_t b = blockIdx.x;
-    if (b < a.nbatches) {
+    if (b < nbatches) {
         issue(0, 0);
         load_samples(b);
         __syncthreads();                                             // waits vmcnt(0) for the DMA, then barrier
@@ -128,7 +151,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
     uint32_t pending = 0u;
     if (tid == 0) pending = gridDim.x + atomicAdd(a.queue, 1u);
 
-    while (b < a.nbatches) {
+    while (b < nbatches) {
         if (tid == 0) {
             claimed = pending;                                       // the wait for the atomic of a batch ago is here
             pending = gridDim.x + atomicAdd(a.queue, 1u);
@@ -141,11 +164,12 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
             for (int s = 0; s < S; ++s) centre_fragment<R1 / 8, 2>(xf[s], mu_lds, h);
         }
         uint64_t sample[S];
-        uint32_t lab[S];
+        uint32_t lab[S], flags[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            sample[s] = ((b * 4 + wave) * S + s) * 32 + s_col;
+            sample[s] = FINISH ? (uint64_t)(sid[s] & CROWD_ID) : ((b * 4 + wave) * S + s) * 32 + s_col;
             lab[s] = label[s];
+            flags[s] = FINISH ? sid[s] : 0u;
         }
 
         f32x4 yf[S][RS / 8];                                          // search-stage fragments
@@ -177,7 +201,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         auto step = [&](auto &&compute) {
             const bool wrap = q + 1 == ngroups;
             VQ_LAP(3);                     // 3: everything outside the three phases of a stage
-            if (!(wrap && bnext >= a.nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);   // nothing to stage after the last batch
+            if (!(wrap && bnext >= nbatches)) issue(wrap ? 0u : q + 1, cur ^ 1);   // nothing to stage after the last batch
             VQ_LAP(0);                     // 0: issue of the next stage's DMA
             if (MODE == MODE_OMEGA && q == (uint32_t)NG1) {
                 // x is dead: the next batch's rows are fetched now and arrive while the search runs.  vmcnt
@@ -239,6 +263,14 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
 #pragma unroll
             for (int s = 0; s < S; ++s) split_fragment<RS>(yf[s], bh[s], bl[s]);
         }
+        // FINISH: the searches every sample was marked for; margin +INF: every row is measured (the exact scan)
+        auto hit_margin = [&](int s, uint32_t which) {
+            if (!FINISH || !(flags[s] & (which | CROWD_ALL))) return -INFINITY;
+            return (flags[s] & CROWD_ALL) || unsafe[s] ? INFINITY : margin[s];
+        };
+        HitKeys<RS, MATCHED, ROOT, 2> hits0(yf[0], a.plain, a.ldp, a.K, hit_margin(0, CROWD_P), hit_margin(0, CROWD_N));
+        HitKeys<RS, MATCHED, ROOT, 2> hits1(yf[S - 1], a.plain, a.ldp, a.K, hit_margin(S - 1, CROWD_P), hit_margin(S - 1, CROWD_N));
+        static_assert(S <= 2, "one HitKeys per sample tile of the wave");
         const uint32_t nsearch = MODE == MODE_OMEGA ? a.ngroups2 : a.ngroups1;
         for (uint32_t qs = 0; qs < nsearch; ++qs) {
             step([&](const float *stage) {
@@ -285,7 +317,10 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                             ou[s] = ku[s];
                             om[s] = km[s];
                         }
-                        if constexpr (GRP) {
+                        if constexpr (FINISH) {
+                            hits0.template tile<1>(acc[0], tile_id, tile + G2::W_FLOATS, lab[0], h);
+                            if constexpr (S == 2) hits1.template tile<1>(acc[S - 1], tile_id, tile + G2::W_FLOATS, lab[S - 1], h);
+                        } else if constexpr (GRP) {
 #pragma unroll
                             for (int s = 0; s < S; ++s) {
                                 GroupKeys<MATCHED> scr{ku[s], km[s]};
@@ -324,6 +359,24 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         }
 
         // ---- epilogue: lane pair (s, h=0/1) agrees on the candidates, re-measures them exactly, stores
+        if constexpr (FINISH) {
+            hits0.merge();
+            hits1.merge();
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const Best1 &wp = s == 0 ? hits0.wp : hits1.wp, &wn = s == 0 ? hits0.wn : hits1.wn;
+                if (flags[s] & (CROWD_P | CROWD_ALL)) {
+                    if (h == 0) {
+                        if (a.out.idx) a.out.idx[sample[s]] = wp.i;
+                    } else if (a.out.dist) a.out.dist[sample[s]] = wp.d;
+                }
+                if (MATCHED && (flags[s] & (CROWD_N | CROWD_ALL))) {
+                    if (h == 0) {
+                        if (a.out.jneg) a.out.jneg[sample[s]] = wn.i;
+                    } else if (a.out.dneg) a.out.dneg[sample[s]] = wn.d;
+                }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const bool live = sample[s] < a.N;
@@ -340,7 +393,8 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                 // each group: best two of the pair's four by (key, index), both re-measured; a third key within the
                 // margin of the best sends the sample to the exact scan (the guarantee: finish_keys, mfma_device.h)
                 const bool skip = rescan;
-                auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w) {
+                bool all = rescan, cp = false, cn = false;             // what the sample is marked for (crowd_mark) or scanned for
+                auto group = [&](uint32_t b1, uint32_t t1, uint32_t b2, uint32_t t2, uint32_t b3, Best1 &w, bool &crowded) {
                     uint32_t f, fi, sd, si;
                     merge_pair(b1, t1, b2, t2, h, f, fi, sd, si);
                     const float third = pair_third(b1, b2, b3);
@@ -352,23 +406,27 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                             const float d2 = measure(si);
                             if (lexless(d2, si, d1, fi)) { w.d = d2; w.i = si; }
                         }
-                        rescan |= !(third - __builtin_bit_cast(float, f) > margin[s]) || !(w.d < INFINITY);
+                        crowded = !(third - __builtin_bit_cast(float, f) > margin[s]);
+                        all |= !(w.d < INFINITY);
                     }
                     return have;
                 };
+                const uint64_t tile32 = (b * 4 + wave) * S + s;        // this tile of 32 samples in the launch
                 if constexpr (GRP) {
                     finish_groups<MATCHED>(
                         h, unsafe[s], margin[s], ku[s], km[s], wp, wn, measure,
                         [&](uint32_t k, bool positive) { return k < a.K && (!MATCHED || (a.cls[k] == lab[s]) == positive); },
-                        [&]() { exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn); });
+                        [&]() { exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn); }, nullptr,
+                        a.crowd_mask, tile32, a.N);
                 } else {
                 if (!MATCHED) {
-                    if (!group(ku[s].b1, ku[s].t1, ku[s].b2, ku[s].t2, ku[s].b3, wp)) rescan = true;
+                    if (!group(ku[s].b1, ku[s].t1, ku[s].b2, ku[s].t2, ku[s].b3, wp, cp)) all = true;
                 } else {
-                    group(km[s].p, km[s].tp, km[s].p2, km[s].tp2, km[s].p3, wp);
-                    group(km[s].n, km[s].tn, km[s].n2, km[s].tn2, km[s].n3, wn);
+                    group(km[s].p, km[s].tp, km[s].p2, km[s].tp2, km[s].p3, wp, cp);
+                    group(km[s].n, km[s].tn, km[s].n2, km[s].tn2, km[s].n3, wn, cn);
                 }
-                if (rescan) exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn);
+                if (!crowd_mark(a.crowd_mask, tile32, a.N, cp, cn, all, h) && (cp || cn || all))
+                    exact_scan<RS, ROOT>(yf[s], a.plain, a.ldp, a.K, h, a.cls, MATCHED, lab[s], wp, wn);
                 }
             }
             if (live) {
@@ -380,6 +438,7 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     if (MATCHED && a.out.dneg) a.out.dneg[sample[s]] = wn.d;
                 }
             }
+        }
         }
         if (MODE != MODE_OMEGA) load_samples(bnext);
         b = bnext;
@@ -433,6 +492,23 @@ hipError_t launch_t(const EngineArgs &a, bool matched, hipStream_t st)
     return hipGetLastError();
 }
 
+// the finish pass (k_engine FINISH): one workgroup per batch of the list, at most the first pass's grid
+template <int MODE, int R1, int R2, int S, int WPS = (R1 >= 256 ? 1 : 2)>
+hipError_t launch_finish_t(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    if constexpr (MODE != MODE_LOCAL && (MODE == MODE_OMEGA ? R2 : R1) <= 128) {
+        const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+        if (e != hipSuccess) return e;
+        const unsigned grid = 256u * WPS;
+        if (matched)
+            hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, true, WPS, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_engine<MODE, R1, R2, S, false, WPS, true, false, true>), dim3(grid), dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int MODE, int R1, int R2, int S>
 bool pick(int mode, int r1, int r2, LaunchFn &fn, int *samples_per_batch)
 {
@@ -441,7 +517,23 @@ bool pick(int mode, int r1, int r2, LaunchFn &fn, int *samples_per_batch)
     *samples_per_batch = 4 * S * 32;                                  // 4 waves x S tiles x 32 samples
     return true;
 }
+template <int MODE, int R1, int R2, int S>
+bool pick_finish(int mode, int r1, int r2, LaunchFn &fn)
+{
+    if (mode != MODE || r1 != R1 || (MODE == MODE_OMEGA && r2 != R2)) return false;
+    fn = &launch_finish_t<MODE, R1, R2, S>;
+    return true;
+}
 }  // namespace
+
+// the Euclidean engines whose search rows are 64 or 128 values long (shorter ones run on group keys, which settle most
+// crowded samples in the first pass; the Omega engines scan in their waves)
+LaunchFn streamed_finish_launcher(int mode, int R1, int R2)
+{
+    LaunchFn fn = nullptr;
+    (void)(pick_finish<MODE_EUCLID, 64, 64, 2>(mode, R1, R2, fn) || pick_finish<MODE_EUCLID, 128, 128, 1>(mode, R1, R2, fn));
+    return fn;
+}
 
 LaunchFn streamed_launcher(int mode, int R1, int R2, int *spb)
 {

@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 // the searches this sample was marked for; margin +INF: every row is measured (the exact scan)
                 const uint32_t flags = sid[q];
                 const float mall = (flags & CROWD_ALL) || unsafe ? INFINITY : margin;
-                HitKeys<R, MATCHED, true, !BFIMG> hits(xf, BFIMG ? a.plain : img, a.ldp, a.K, flags & (CROWD_P | CROWD_ALL) ? mall : -INFINITY,
+                HitKeys<R, MATCHED, true, BFIMG ? 0 : 1> hits(xf, BFIMG ? a.plain : img, a.ldp, a.K, flags & (CROWD_P | CROWD_ALL) ? mall : -INFINITY,
                                                       flags & (CROWD_N | CROWD_ALL) ? mall : -INFINITY);
                 {
                     u32x4 bh[R / 16], bl[R / 16];

@@ -1017,6 +1017,23 @@ __device__ __forceinline__ float exact_part_g(const f32x4 (&xf)[R / 8], const fl
     }
     return p[0] + p[1];
 }
+// (exact_sq's order: one chain -- the streamed engine's re-measurement)
+template <int R>
+__device__ __forceinline__ float exact_part_chain(const f32x4 (&xf)[R / 8], const float *plain, uint32_t ldp, uint32_t k, int h)
+{
+    const float *w = plain + (size_t)k * ldp;
+    float p = 0.0f;
+#pragma unroll
+    for (int j = 0; j < R / 8; ++j) {
+        const f32x4 wv = *(const f32x4 *)(w + 4 * (2 * j + h));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = wv[e] - xf[j][e];
+            p = fmaf(d, d, p);
+        }
+    }
+    return p;
+}
 
 // ------------------------------------------------------------------------------ screening policies of the bf16 tile loops
 // What happens to the 16 finished scores a lane holds for one tile (rows 8 g + 4 h + e of the tile, register 4 g + e) is a
@@ -1133,8 +1150,10 @@ struct GroupKeys {
 // minimum would ask for; the lane pair's two lists are merged by (distance, index) at the end.  A row is measured by
 // BOTH lanes of its pair (each holds half of the sample's chunks), so hits are worked one score register at a time with
 // the partner's row number exchanged.  margin = +INF (unusable scores) makes every row a hit: the exact scan.
-//   LDSROWS  the exact rows come from the f32 image in LDS (rows = the image), else from the plain matrix (K x ldp)
-template <int R, bool MATCHED, bool ROOT, bool LDSROWS>
+//   ROWS  where the exact rows come from, and in which order a row is summed (the first pass's: a distance must not depend
+//         on the pass that measured it): 1 the f32 image in LDS (rows = the image, exact_sq_lds), 0 the plain matrix
+//         (K x ldp) as exact_sq_g sums it, 2 the plain matrix as exact_sq does
+template <int R, bool MATCHED, bool ROOT, int ROWS>
 struct HitKeys {
     const f32x4 (&xf)[R / 8];
     const float *rows;
@@ -1146,7 +1165,8 @@ struct HitKeys {
         : xf(xf_), rows(rows_), ldp(ldp_), K(K_), margin_p(mp), margin_n(mn) {}
     __device__ __forceinline__ float part(uint32_t k, int h) const
     {
-        if constexpr (LDSROWS) return exact_part_lds<R>(xf, rows, k, h);
+        if constexpr (ROWS == 1) return exact_part_lds<R>(xf, rows, k, h);
+        else if constexpr (ROWS == 2) return exact_part_chain<R>(xf, rows, ldp, k, h);
         else return exact_part_g<R>(xf, rows, ldp, k, h);
     }
     template <int PRE>
