@@ -225,11 +225,16 @@ def measure_traffic(workload, rows, kernel_fn):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode})"
-            got = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
-                   if ("vq::" + kernel_fn + "<") in r["Kernel_Name"] and r["Counter_Name"] == counter]
-            if not got:
+            by_name = {}                       # per instantiation: the finish pass is another one of the same template
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if ("vq::" + kernel_fn + "<") in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        by_name.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not by_name:
                 return None, f"no {counter} rows for {kernel_fn}"
-            vals[counter] = sum(got) / len(got)
+            # per step: every instantiation's launches count (first pass + finish pass), over the first pass's launches
+            first = max(by_name.values(), key=sum)
+            vals[counter] = sum(sum(v) for v in by_name.values()) / len(first)
         finally:
             shutil.rmtree(out, ignore_errors=True)
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "live pmc: 2*FETCH_SIZE+WRITE_SIZE KiB"

@@ -19,15 +19,19 @@ shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 dom = max(rows, key=lambda r: float(r["TotalDurationNs"]))
 
-def counter(kind, name_part):
+def counter(kind, name_part, exact=None):
     f = max(glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")), key=os.path.getmtime)
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if name_part in r["Kernel_Name"]]
-    return vals
+    recs = list(csv.DictReader(open(f)))
+    if exact is not None:        # the dominant instantiation only (the finish pass is another instantiation of the same template)
+        vals = [float(r["Counter_Value"]) for r in recs if r["Kernel_Name"] == exact]
+        if vals:
+            return vals
+    return [float(r["Counter_Value"]) for r in recs if name_part in r["Kernel_Name"]]
 
 import re
 dom_fn = re.search(r"vq::(k_\w+)", dom["Name"]).group(1)      # counters of the dominant kernel only
-fetch = counter("pmc_fetch", "vq::" + dom_fn + "<")
-write = counter("pmc_write", "vq::" + dom_fn + "<")
+fetch = counter("pmc_fetch", "vq::" + dom_fn + "<", dom["Name"])
+write = counter("pmc_write", "vq::" + dom_fn + "<", dom["Name"])
 synth_w = counter("pmc_write", "k_synth_fill")
 out = {
     "workload": workload,
