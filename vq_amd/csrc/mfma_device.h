@@ -326,6 +326,28 @@ __device__ __forceinline__ void screen16(const f32x16 &sc, Keys2 &ku)
         : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [b3] "+v"(ku.b3), [t0] "=&v"(t0), [t1] "=&v"(t1)
         : [s0] "v"(sc[0]), [s1] "v"(sc[1]), [s2] "v"(sc[2]), [s3] "v"(sc[3]), [s4] "v"(sc[4]), [s5] "v"(sc[5]), [s6] "v"(sc[6]), [s7] "v"(sc[7]), [s8] "v"(sc[8]), [s9] "v"(sc[9]), [s10] "v"(sc[10]), [s11] "v"(sc[11]), [s12] "v"(sc[12]), [s13] "v"(sc[13]), [s14] "v"(sc[14]), [s15] "v"(sc[15]), [m] "s"(0xFFFFFFF0u));
 }
+// ONE of a tile's 16 scores (register O) offered the same way: screen16 cut into pieces that sit between the MFMAs of the
+// next tile (pieces_step).  The keys of a tile are distinct patterns (position bits), so the best three do not depend on
+// the order they are offered in.
+template <int O, int PRE_NOPS>
+__device__ __forceinline__ void screen1(const f32x16 &sc, Keys2 &ku)
+{
+    uint32_t t0;
+#define VQ_SCREEN1_TEXT                                \
+    "v_and_or_b32 %[t0], %[s0], %[m], %[o0]\n\t"       \
+    "v_med3_f32 %[b3], %[b2], %[b3], %[t0]\n\t"        \
+    "v_med3_f32 %[b2], %[b1], %[b2], %[t0]\n\t"        \
+    "v_min_f32 %[b1], %[b1], %[t0]\n\t"
+    if constexpr (PRE_NOPS > 0)
+        asm volatile("s_nop 15\n\ts_nop 1\n\t" VQ_SCREEN1_TEXT
+                     : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [b3] "+v"(ku.b3), [t0] "=&v"(t0)
+                     : [s0] "v"(sc[O]), [m] "s"(0xFFFFFFF0u), [o0] "n"(O));
+    else
+        asm volatile(VQ_SCREEN1_TEXT
+                     : [b1] "+v"(ku.b1), [b2] "+v"(ku.b2), [b3] "+v"(ku.b3), [t0] "=&v"(t0)
+                     : [s0] "v"(sc[O]), [m] "s"(0xFFFFFFF0u), [o0] "n"(O));
+#undef VQ_SCREEN1_TEXT
+}
 // After a tile's scores went in: which tile do the best two keys come from now
 __device__ __forceinline__ void settle_tiles(Keys2 &ku, const Keys2 &before, uint32_t tile_id)
 {
@@ -1051,6 +1073,36 @@ template <bool MATCHED>
 struct TopKeys {
     Keys2 ku;
     KeysM km;
+    // The screening can be spread over the MFMAs of the next tile (pieces_step): begin(), one<O>() for each of the 16
+    // scores, end() -- together exactly tile<>().  Measured on one box: config 2 4.25 -> 4.40e9 samples/s, config 3
+    // 2.53 -> 2.57e9; the labelled form (10 vector instructions per score, bound by their issue either way) lost 1.7 %
+    // to the pinning and keeps its block.
+    static constexpr bool SPREAD = !MATCHED;
+    Keys2 before;
+    KeysM before_m;
+    __device__ __forceinline__ void begin()
+    {
+        if constexpr (MATCHED) before_m = km;
+        else before = ku;
+    }
+    template <int O, int PRE>
+    __device__ __forceinline__ void one(f32x16 &sc, const float *tail, uint32_t label, int h)
+    {
+        if constexpr (!MATCHED) {
+            screen1<O, PRE>(sc, ku);
+        } else {
+            if constexpr (PRE != 0) settle_mfma(sc);
+            const uint32_t *tcls = (const uint32_t *)tail + 32 + 4 * h;
+            const uint32_t key = pack_key(sc[O], O);
+            const bool match = tcls[8 * (O >> 2) + (O & 3)] == label;              // helpers.rs:113 / :122
+            offer_m(km, match ? key : KEY_NONE, match ? KEY_NONE : key);
+        }
+    }
+    __device__ __forceinline__ void end(uint32_t tile_id)
+    {
+        if constexpr (MATCHED) settle_tiles_m(km, before_m, tile_id);
+        else settle_tiles(ku, before, tile_id);
+    }
     template <int PRE>
     __device__ __forceinline__ void tile(f32x16 &sc, uint32_t tile_id, const float *tail, uint32_t label, int h)
     {
@@ -1116,6 +1168,11 @@ __device__ __forceinline__ float group_min(float s0, float s1, float s2, float s
 
 template <bool MATCHED>
 struct GroupKeys {
+    static constexpr bool SPREAD = false;
+    __device__ __forceinline__ void begin() {}                       // (the spread form is TopKeys' alone)
+    template <int O, int PRE>
+    __device__ __forceinline__ void one(f32x16 &, const float *, uint32_t, int) {}
+    __device__ __forceinline__ void end(uint32_t) {}
     Keys2 ku;
     KeysM km;
     template <int PRE>
@@ -1155,6 +1212,11 @@ struct GroupKeys {
 //         (K x ldp) as exact_sq_g sums it, 2 the plain matrix as exact_sq does
 template <int R, bool MATCHED, bool ROOT, int ROWS>
 struct HitKeys {
+    static constexpr bool SPREAD = false;
+    __device__ __forceinline__ void begin() {}                       // (the spread form is TopKeys' alone)
+    template <int O, int PRE>
+    __device__ __forceinline__ void one(f32x16 &, const float *, uint32_t, int) {}
+    __device__ __forceinline__ void end(uint32_t) {}
     const f32x4 (&xf)[R / 8];
     const float *rows;
     uint32_t ldp, K;
@@ -1254,13 +1316,34 @@ __device__ __forceinline__ void pieces_step(const char *ptile, const char *pnext
             pl = *(const u32x4 *)(pnext + row * ROWB + h * 32 + 16);
         }
         const bf16x8 vh = __builtin_bit_cast(bf16x8, ch), vl = __builtin_bit_cast(bf16x8, cl);
+        // The screening of the previous tile: one asm block behind the first step -- or (SPREAD) PER scores behind every MFMA
+        // from the second of the tile on, pinned there (sched_barrier): the MFMAs of a tile are one dependent chain, the
+        // wave issues in order, so only vector work that stands BETWEEN two of them runs under the first one's 32 cycles.
+        // prev's last MFMA sits one MFMA and 18 wait states in front of its first reader (8 passes ask for 11; nothing pads
+        // hazards for inline asm).
+        constexpr bool SPREAD = SCR::SPREAD && NQ >= 4;
+        constexpr int PER = NQ >= 8 ? 1 : 2;           // scores per MFMA slot: 16 or 8 slots of the tile's 3 NQ
+        auto slot = [&](auto ii) {
+            constexpr int sidx = 3 * q + decltype(ii)::value;           // MFMA number in the tile
+            if constexpr (SPREAD && sidx >= 1 && (sidx - 1) * PER < 16) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (sidx == 1) scr.begin();
+                static_for<0, PER>([&](auto jj) {
+                    scr.template one<(sidx - 1) * PER + decltype(jj)::value, (sidx == 1 && decltype(jj)::value == 0) ? 1 : 0>(prev, tail_prev, label, h);
+                });
+                if constexpr (sidx * PER == 16) scr.end(tprev_id);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+        slot(std::integral_constant<int, 0>{});
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
+        slot(std::integral_constant<int, 1>{});
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
-        // prev's last MFMA sits three dependent MFMAs back; the wait states are kept all the same (bf16 MFMAs do not hold
-        // up the vector ALUs, and nothing pads hazards for inline asm)
-        if constexpr (q == 0) scr.template tile<1>(prev, tprev_id, tail_prev, label, h);
-        if constexpr (q == NQ / 2) {                   // NQ == 1: q == 0
+        slot(std::integral_constant<int, 2>{});
+        if constexpr (!SPREAD && q == 0) scr.template tile<1>(prev, tprev_id, tail_prev, label, h);
+        // the next tile's init column; SPREAD: once the last score of prev is in (its registers are free then)
+        if constexpr (q == (SPREAD ? (16 / PER) / 3 + 1 : NQ / 2)) {   // NQ == 1: q == 0
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 ci = *(const f32x4 *)(tail_next + 8 * g + 4 * h);
