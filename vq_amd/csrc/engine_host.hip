@@ -48,6 +48,8 @@ struct EngineModel {
     // buffers, one set per launch in flight like the batch counters: [3 mask words per tile of 32 samples][count][ids],
     // sized for the largest launch so far.
     LaunchFn finish = nullptr;
+    float *img_f32 = nullptr;          // bfimg models with a finish pass: the f32 tile image all the same -- the finish pass
+                                       // keeps IT in LDS and measures its hits from there (splitting the tiles as it goes)
     mutable uint32_t *crowd[CROWD_SLOTS] = {};
     mutable uint64_t crowd_rows[CROWD_SLOTS] = {};
     mutable uint32_t next_crowd = 0;
@@ -740,7 +742,7 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         }
     }
 
-    std::vector<float> imgbf;
+    std::vector<float> imgbf, img_f32;
     if (m.bf && m.lds_used != 0) {
         std::vector<float> &simg = m.search_img == 1 ? img1 : img2;
         switch (m.search_R) {
@@ -752,6 +754,7 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         }
         // no room for every tile's pieces beside the f32 image: the image becomes the pieces, the exact rows come from L2
         if (m.nbf < res_tiles(m.K) && m.bfimg_ok && !getenv("VQHIP_NO_BFIMG")) {
+            if (m.finish && m.search_img == 1 && !getenv("VQHIP_FINISH_PIECES")) img_f32 = simg;
             switch (m.search_R) {
             case 16: pieces_image<16>(simg, res_tiles(m.K)); break;
             case 32: pieces_image<32>(simg, res_tiles(m.K)); break;
@@ -767,6 +770,7 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
     EngineModel *out = new EngineModel(m);
     herr = to_device(&out->img1, img1);
     if (herr == hipSuccess && !imgbf.empty()) herr = to_device(&out->imgbf, imgbf);
+    if (herr == hipSuccess && !img_f32.empty()) herr = to_device(&out->img_f32, img_f32);
     if (herr == hipSuccess && !img2.empty()) herr = to_device(&out->img2, img2);
     if (herr == hipSuccess && !plain.empty()) herr = to_device(&out->plain, plain);
     if (herr == hipSuccess && !cls.empty()) herr = to_device(&out->cls, cls);
@@ -792,6 +796,7 @@ void engine_free(EngineModel *m)
     (void)hipFree(m->queue);
     (void)hipFree(m->mu);
     (void)hipFree(m->imgbf);
+    (void)hipFree(m->img_f32);
     for (uint32_t *p : m->crowd) (void)hipFree(p);
     delete m;
 }
@@ -880,6 +885,12 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
             f.list = list;
             f.list_count = count;
             f.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
+            if (m->img_f32) {                                            // the finish pass on the f32 image (hits measured from LDS)
+                f.img1 = m->img_f32;
+                f.bfimg = 0u;
+                f.imgbf = nullptr;
+                f.nbf = 0u;
+            }
             e = m->finish(f, dy != nullptr, s);
             if (e == hipSuccess && getenv("VQHIP_STATS")) {              // diagnostic: how many samples the first pass marked
                 (void)hipStreamSynchronize(s);

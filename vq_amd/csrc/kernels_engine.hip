@@ -61,6 +61,9 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
     constexpr int NG1 = (T1 + G1::G - 1) / G1::G;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
     __shared__ uint32_t claimed;                                     // the batch after this one
+    // FINISH: the lanes' deferred hit lists (HitKeys CAP = 16: 32 words per lane and sample tile, lane-interleaved)
+    constexpr int HIT_CAP = 16;
+    __shared__ uint32_t hit_lds[FINISH ? S * 2 * HIT_CAP * 256 : 1];
     __shared__ __attribute__((aligned(16))) float mu_lds[R1];
     stage_centre<R1>(mu_lds, a.mu, threadIdx.x, 256);                // published by the first barrier below
 
@@ -268,8 +271,10 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
             if (!FINISH || !(flags[s] & (which | CROWD_ALL))) return -INFINITY;
             return (flags[s] & CROWD_ALL) || unsafe[s] ? INFINITY : margin[s];
         };
-        HitKeys<RS, MATCHED, ROOT, 2> hits0(yf[0], a.plain, a.ldp, a.K, hit_margin(0, CROWD_P), hit_margin(0, CROWD_N));
-        HitKeys<RS, MATCHED, ROOT, 2> hits1(yf[S - 1], a.plain, a.ldp, a.K, hit_margin(S - 1, CROWD_P), hit_margin(S - 1, CROWD_N));
+        HitKeys<RS, MATCHED, ROOT, 2, HIT_CAP> hits0(yf[0], a.plain, a.ldp, a.K, hit_margin(0, CROWD_P), hit_margin(0, CROWD_N),
+                                                     hit_lds + (FINISH ? tid : 0), 256u);
+        HitKeys<RS, MATCHED, ROOT, 2, HIT_CAP> hits1(yf[S - 1], a.plain, a.ldp, a.K, hit_margin(S - 1, CROWD_P), hit_margin(S - 1, CROWD_N),
+                                                     hit_lds + (FINISH ? (S - 1) * 2 * HIT_CAP * 256 + tid : 0), 256u);
         static_assert(S <= 2, "one HitKeys per sample tile of the wave");
         const uint32_t nsearch = MODE == MODE_OMEGA ? a.ngroups2 : a.ngroups1;
         for (uint32_t qs = 0; qs < nsearch; ++qs) {

@@ -188,7 +188,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         if (count > a.N) count = (uint32_t)a.N;       // (never more entries than rows)
         if (count == 0) return;                        // nothing was marked: not even the image is loaded
     }
-    const uint64_t nbatches = FINISH ? ((uint64_t)count + 31) / 32 : a.nbatches;
+    // FINISH: a list of fewer than 32 samples per wave is spread THIN -- spb samples to a wave (lanes s_col < spb), one
+    // batch per wave, no queue: a batch's time is its hits' round trips to the exact rows one after the other, whoever's
+    // they are, and then the walk over the dry counters (191 marked samples of 10M as 6 full batches on 3 waves: 241 us).
+    // Thin: wave w works entries [w spb, (w + 1) spb) as batch 2 w; the odd batches are empty.
+    uint32_t spb = 32;
+    bool thin = false;
+    if constexpr (FINISH) {
+        const uint32_t waves = gridDim.x * NW;
+        if (count < 32u * waves) {
+            thin = true;
+            spb = (count + waves - 1) / waves;         // 1 .. 32
+        }
+    }
+    const uint64_t nbatches = !FINISH ? a.nbatches : thin ? 2 * (((uint64_t)count + spb - 1) / spb) : ((uint64_t)count + 31) / 32;
     // FINISH: the batches are dealt across the workgroups first (wave w of workgroup g starts on block w * groups + g): a
     // short list keeps one wave per CU busy instead of eight on a few CUs, and a workgroup whose first wave finds
     // nothing returns before it loads the image
@@ -251,7 +264,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
     const uint32_t wave_id = FINISH ? wave_u * gridDim.x + blockIdx.x : blockIdx.x * NW + wave_u;
     BlockQueue<BLOCK> queue(a.queue, lane, wave_id, gridDim.x * NW, nbatches);
     uint64_t block0 = (uint64_t)wave_id * BLOCK;
-    queue.request();
+    if (!thin) queue.request();                        // (thin: every batch has its wave, nothing is claimed)
     // Rows come in through a buffer descriptor rebased per batch (wave-uniform, so the 4 GiB offset
     // range is per batch, not per matrix): rows past N read as zeros by the hardware range check, one
     // per-lane offset serves every chunk (immediate offsets), and nothing needs a 64-bit address.
@@ -281,8 +294,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
         constexpr int fset = SETS == 1 ? 0 : q;
         if constexpr (FINISH) {
             // entry of this lane pair's sample; slots past the list read entry 0 with no flags (searched, never stored)
-            const uint64_t slot = bb * 32 + (uint64_t)s_col;
-            uint32_t e = slot < count ? a.list[slot] : 0u;
+            const uint64_t slot = (thin ? bb / 2 : bb) * spb + (uint64_t)s_col;
+            uint32_t e = (uint32_t)s_col < spb && !(thin && (bb & 1)) && slot < count ? a.list[slot] : 0u;
             if ((e & CROWD_ID) >= a.N) e = 0u;         // (an id that is no row: searched as row 0, never stored)
             sid[q] = e;
             const float *row = a.X + (size_t)(e & CROWD_ID) * a.D;
@@ -322,9 +335,10 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                                       (MATCHED ? (a.out.jneg ? 1u : 0u) + (a.out.dneg ? 1u : 0u) : 0u);
     uint32_t stores_behind = 0u;                       // STAGED: store instructions issued after the pieces now in flight
     while (block0 < nbatches) {                       // the last block may end past nbatches: such a batch reads zeros, stores nothing
-        const uint64_t nb0 = queue.take();             // first batch of the next block (the wait for its atomic is here)
+        const uint64_t nb0 = thin ? nbatches : queue.take();   // first batch of the next block (the wait for its atomic is here)
         static_for<0, (int)BLOCK>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
+            if (FINISH && thin && q != 0) return;      // (the odd batches of a thin list are empty)
             constexpr int set = SETS == 1 ? 0 : q;
             const uint64_t b = block0 + q;
             f32x4(&xf)[R / 8] = x[set];
@@ -367,7 +381,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
             // vmcnt counts in issue order: the atomic goes out only after this batch's rows have been waited
             // for, or that wait would include the atomic's own round trip
             asm volatile("" ::: "memory");
-            if constexpr (q == 0) queue.request();     // the block after the one just taken
+            if constexpr (q == 0) {
+                if (!thin) queue.request();            // the block after the one just taken
+            }
             // the staging buffer is free again; the label goes to the slot of the batch it belongs to
             if constexpr (STAGED) fetch(std::integral_constant<int, (q + 1) % (int)BLOCK>{}, q + 1 < (int)BLOCK ? b + 1 : nb0);
             lap(1);                                    // 1: issue of the claim / of the staged variant's next pieces
@@ -376,7 +392,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_resident_pipe(const EngineA
                 // the searches this sample was marked for; margin +INF: every row is measured (the exact scan)
                 const uint32_t flags = sid[q];
                 const float mall = (flags & CROWD_ALL) || unsafe ? INFINITY : margin;
-                HitKeys<R, MATCHED, true, BFIMG ? 0 : 1> hits(xf, BFIMG ? a.plain : img, a.ldp, a.K, flags & (CROWD_P | CROWD_ALL) ? mall : -INFINITY,
+                HitKeys<R, MATCHED, true, BFIMG ? 0 : 1, 8> hits(xf, BFIMG ? a.plain : img, a.ldp, a.K, flags & (CROWD_P | CROWD_ALL) ? mall : -INFINITY,
                                                       flags & (CROWD_N | CROWD_ALL) ? mall : -INFINITY);
                 {
                     u32x4 bh[R / 16], bl[R / 16];

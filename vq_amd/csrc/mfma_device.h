@@ -1210,78 +1210,156 @@ struct GroupKeys {
 //   ROWS  where the exact rows come from, and in which order a row is summed (the first pass's: a distance must not depend
 //         on the pass that measured it): 1 the f32 image in LDS (rows = the image, exact_sq_lds), 0 the plain matrix
 //         (K x ldp) as exact_sq_g sums it, 2 the plain matrix as exact_sq does
-template <int R, bool MATCHED, bool ROOT, int ROWS>
+//   CAP   0: a tile's hits are measured on the spot, one round trip to the exact rows per hit of the tile's busiest lane.
+//         16: hits go to a per-lane list in LDS (row | side << 31, score; `lst` + i * 2 * stride) and are measured when a
+//         list could overflow and at the end -- as many round trips as the busiest lane has hits in ALL, not per tile (with
+//         thousands of prototypes nearly every tile holds some sample's hit), and by then the threshold has come down: an
+//         entry whose score is above the running minimum + margin of the moment it is read is dropped unmeasured.
+//         8: the same with the list in eight registers of the lane (no scores: nothing is dropped), for kernels whose LDS
+//         is taken; a tile that brings a lane more than 8 hits (the exact scan: all 16) is measured on the spot.
+template <int R, bool MATCHED, bool ROOT, int ROWS, int CAP = 0>
 struct HitKeys {
+    static_assert(CAP == 0 || CAP == 8 || CAP == 16, "0: on the spot, 8: register list, 16: LDS list");
+    uint32_t ids[CAP == 8 ? 8 : 1] = {};   // CAP == 8: the list (row | side << 31)
     static constexpr bool SPREAD = false;
     __device__ __forceinline__ void begin() {}                       // (the spread form is TopKeys' alone)
     template <int O, int PRE>
     __device__ __forceinline__ void one(f32x16 &, const float *, uint32_t, int) {}
     __device__ __forceinline__ void end(uint32_t) {}
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
     const f32x4 (&xf)[R / 8];
     const float *rows;
     uint32_t ldp, K;
     float margin_p, margin_n;          // -INF: the search is not this sample's problem (no hits, nothing stored)
     float run_p = INFINITY, run_n = INFINITY;
     Best1 wp, wn;
-    __device__ __forceinline__ HitKeys(const f32x4 (&xf_)[R / 8], const float *rows_, uint32_t ldp_, uint32_t K_, float mp, float mn)
-        : xf(xf_), rows(rows_), ldp(ldp_), K(K_), margin_p(mp), margin_n(mn) {}
+    uint32_t *lst;                     // CAP != 0: this lane's list
+    uint32_t stride, cnt = 0u;
+    int hh = 0;
+    __device__ __forceinline__ HitKeys(const f32x4 (&xf_)[R / 8], const float *rows_, uint32_t ldp_, uint32_t K_, float mp, float mn,
+                                       uint32_t *lst_ = nullptr, uint32_t stride_ = 0u)
+        : xf(xf_), rows(rows_), ldp(ldp_), K(K_), margin_p(mp), margin_n(mn), lst(lst_), stride(stride_) {}
     __device__ __forceinline__ float part(uint32_t k, int h) const
     {
         if constexpr (ROWS == 1) return exact_part_lds<R>(xf, rows, k, h);
         else if constexpr (ROWS == 2) return exact_part_chain<R>(xf, rows, ldp, k, h);
         else return exact_part_g<R>(xf, rows, ldp, k, h);
     }
+    // One step for the whole wave: every lane's row `mine` (< K, or NONE) measured exactly and offered.  A row is measured
+    // by BOTH lanes of its pair (each holds half of the sample's chunks): row numbers and partial sums are exchanged.
+    // No branch around the loads -- a lane without a row reads row 0 and drops the sum -- so the two rows' loads go out
+    // together: one round trip per step, not two.
+    __device__ __forceinline__ void measure(uint32_t mine, bool positive, int h)
+    {
+        const uint32_t theirs = xor32(mine);
+        const float pm = part(mine != NONE ? mine : 0u, h);
+        const float pt = part(theirs != NONE ? theirs : 0u, h);
+        const float got = xor32(pt);                                                   // the partner's part of MY row
+        if (mine != NONE) {
+            const float total = pm + got;
+            const float d = ROOT ? sqrtf(total) : total;
+            if (positive) wp.offer(d, mine);
+            else wn.offer(d, mine);
+        }
+    }
+    // the listed hits, oldest first (index order inside a lane), against the thresholds as they stand now
+    __device__ __forceinline__ void drain()
+    {
+        if constexpr (CAP == 8) {
+            static_for<0, 8>([&](auto ii) {
+                constexpr uint32_t i = (uint32_t)decltype(ii)::value;
+                if (__builtin_amdgcn_ballot_w64(i < cnt) != 0ull) {
+                    const uint32_t e = ids[i];
+                    measure(i < cnt ? (e & 0x7FFFFFFFu) : NONE, (e >> 31) == 0u, hh);
+                }
+            });
+            cnt = 0u;
+        } else if constexpr (CAP != 0) {
+            const float thr_p = run_p + margin_p, thr_n = run_n + margin_n;
+            for (uint32_t i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0ull; ++i) {
+                const bool have = i < cnt;
+                const uint32_t e = have ? lst[(2u * i) * stride] : 0u;
+                const float sc = __builtin_bit_cast(float, have ? lst[(2u * i + 1u) * stride] : 0u);
+                const bool positive = (e >> 31) == 0u;
+                const bool keep = have && !(sc > (positive ? thr_p : thr_n));
+                if (__builtin_amdgcn_ballot_w64(keep) != 0ull) measure(keep ? (e & 0x7FFFFFFFu) : NONE, positive, hh);
+            }
+            cnt = 0u;
+        }
+    }
     template <int PRE>
     __device__ __forceinline__ void tile(f32x16 &sc, uint32_t tile_id, const float *tail, uint32_t label, int h)
     {
         if constexpr (PRE != 0) settle_mfma(sc);
+        hh = h;
         const uint32_t *tcls = (const uint32_t *)tail + 32 + 4 * h;
         bool match[16];
+        float val[16];                                 // (plain floats: bit casts of vector elements have been miscompiled, 4.11)
         // running minima first (they include this tile), then the thresholds
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
             match[o] = !MATCHED || tcls[8 * (o >> 2) + (o & 3)] == label;             // helpers.rs:113 / :122
             const float v = sc[o];
+            val[o] = v;
             if (match[o]) run_p = fminf(run_p, v);
             else run_n = fminf(run_n, v);
         }
         const bool en_p = margin_p > -INFINITY, en_n = margin_n > -INFINITY;
         const float thr_p = run_p + margin_p, thr_n = run_n + margin_n;
-        bool any = false;
         bool hit[16];
+        uint32_t hm = 0u, mm = 0u;
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
-            hit[o] = (match[o] ? en_p : en_n) && !(sc[o] > (match[o] ? thr_p : thr_n));   // NaN scores count as hits: measured, never win
-            any |= hit[o];
+            const uint32_t k = tile_id * 32u + 8u * (uint32_t)(o >> 2) + 4u * (uint32_t)h + (uint32_t)(o & 3);
+            // NaN scores count as hits: measured, never win.  Rows past K (pad rows of the last tile) are nobody's hit.
+            hit[o] = (match[o] ? en_p : en_n) && !(val[o] > (match[o] ? thr_p : thr_n)) && k < K;
+            hm |= hit[o] ? 1u << o : 0u;
+            mm |= match[o] ? 1u << o : 0u;
         }
-        if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;
-        // One step measures, for every lane, the first of ITS remaining hits of this tile (rows in index order inside a
-        // lane): as many steps as the busiest lane has hits, not one per score register -- every step is a round trip to
-        // the exact rows for the whole wave.
-        uint32_t hm = 0u;
-#pragma unroll
-        for (int o = 0; o < 16; ++o) hm |= hit[o] ? 1u << o : 0u;
-        while (__builtin_amdgcn_ballot_w64(hm != 0u) != 0ull) {
-            const uint32_t o = hm != 0u ? (uint32_t)__builtin_ctz(hm) : 0u;
-            const uint32_t k = tile_id * 32u + 8u * (o >> 2) + 4u * (uint32_t)h + (o & 3u);
-            const uint32_t mine = hm != 0u && k < K ? k : 0xFFFFFFFFu;
-            hm &= hm - 1u;
-            const uint32_t theirs = xor32(mine);
-            const float pm = mine != 0xFFFFFFFFu ? part(mine, h) : 0.0f;
-            const float pt = theirs != 0xFFFFFFFFu ? part(theirs, h) : 0.0f;
-            const float got = xor32(pt);                                               // the partner's part of MY row
-            if (mine != 0xFFFFFFFFu) {
-                const float total = pm + got;
-                const float d = ROOT ? sqrtf(total) : total;
-                const bool mine_matches = !MATCHED || tcls[8u * (o >> 2) + (o & 3u)] == label;
-                if (mine_matches) wp.offer(d, k);
-                else wn.offer(d, k);
+        if (__builtin_amdgcn_ballot_w64(hm != 0u) == 0ull) return;
+        // one step per hit of the tile's busiest lane: measured on the spot (CAP == 0), or put on the lane's register list
+        auto each_hit = [&](auto &&what) {
+            while (__builtin_amdgcn_ballot_w64(hm != 0u) != 0ull) {
+                const uint32_t o = hm != 0u ? (uint32_t)__builtin_ctz(hm) : 0u;
+                const uint32_t k = tile_id * 32u + 8u * (o >> 2) + 4u * (uint32_t)h + (o & 3u);
+                const uint32_t mine = hm != 0u ? k : NONE;
+                const bool positive = ((mm >> o) & 1u) != 0u;
+                hm &= hm - 1u;
+                what(mine, positive);
             }
+        };
+        if constexpr (CAP == 8) {
+            const uint32_t n = (uint32_t)__builtin_popcount(hm);
+            if (__builtin_amdgcn_ballot_w64(cnt + n > 8u) != 0ull) drain();
+            if (__builtin_amdgcn_ballot_w64(n > 8u) != 0ull) {
+                each_hit([&](uint32_t mine, bool positive) { measure(mine, positive, h); });
+            } else {
+                each_hit([&](uint32_t mine, bool positive) {
+                    const uint32_t e = mine | (positive ? 0u : 0x80000000u);
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) ids[j] = (mine != NONE && cnt == j) ? e : ids[j];
+                    cnt += mine != NONE ? 1u : 0u;
+                });
+            }
+        } else if constexpr (CAP != 0) {
+            if (__builtin_amdgcn_ballot_w64(cnt + (uint32_t)__builtin_popcount(hm) > (uint32_t)CAP) != 0ull) drain();
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                if (hit[o]) {
+                    const uint32_t k = tile_id * 32u + 8u * (uint32_t)(o >> 2) + 4u * (uint32_t)h + (uint32_t)(o & 3);
+                    lst[(2u * cnt) * stride] = k | (match[o] ? 0u : 0x80000000u);
+                    lst[(2u * cnt + 1u) * stride] = __float_as_uint(val[o]);
+                    ++cnt;
+                }
+            }
+        } else {
+            each_hit([&](uint32_t mine, bool positive) { measure(mine, positive, h); });
         }
     }
     // the lane pair's answer
     __device__ __forceinline__ void merge()
     {
+        drain();
         wp.merge_halves();
         wn.merge_halves();
     }
