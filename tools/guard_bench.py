@@ -10,6 +10,8 @@ Cases ("the guard's price where it fires"):
   binary_256    0 / 1 features, K = 256, D = 128 (exact multi-way ties)
   random_1024 / random_4096        uniform random, streamed engine
   pixels_784 / pixels_1024         data in [0, 1), K = 50 / 100: the long-row kernels with the centre subtracted
+  synth_c3 / random_c3, synth_c4 / random_c4   the Omega kernels (k_omega_pipe, k_lowrank_pipe: no finish pass, samples the
+                screening cannot settle are scanned in their wave) on their own clustered data and on uniform random data
 """
 import os
 import sys
@@ -39,6 +41,10 @@ def clustered(rng, K, D, spread_rel):
 
 def make(case, rng, n_host):
     """-> (W, X_host block that is tiled on the device)"""
+    if case in ("random_c3", "random_c4"):
+        D, K, M = (128, 256, 128) if case == "random_c3" else (256, 1024, 16)
+        Om = (rng.uniform(-1, 1, (M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+        return rng.uniform(-1, 1, (K, D)).astype(np.float32), rng.uniform(-1, 1, (n_host, D)).astype(np.float32), Om
     if case == "random_c2":
         return rng.uniform(-1, 1, (256, 128)).astype(np.float32), rng.uniform(-1, 1, (n_host, 128)).astype(np.float32)
     if case == "init_state":
@@ -66,6 +72,7 @@ def make(case, rng, n_host):
     raise SystemExit(f"unknown case {case}")
 
 
+OMEGA_CASES = ["synth_c3", "random_c3", "synth_c4", "random_c4"]
 CASES = ["synth_c2", "random_c2", "init_state", "clustered_256", "clustered_2048", "binary_256", "random_1024", "random_4096",
          "pixels_784", "pixels_1024"]
 
@@ -75,19 +82,22 @@ def main():
     ctx = Context(0)
     for case in cases:
         rng = np.random.default_rng(abs(hash(case)) % (1 << 31))
-        if case == "synth_c2":
-            m = synth.make_model(synth.CONFIGS["c2"])
+        if case.startswith("synth_"):
+            m = synth.make_model(synth.CONFIGS[case.split("_")[1]])
             synth.load_model(ctx, m)
             N = 4_000_000
             X = synth.samples_device(ctx, m, 0, N)
         else:
             n_host = 262_144
-            W, Xh = make(case, rng, n_host)
+            made = make(case, rng, n_host)
+            W, Xh = made[0], made[1]
             D = W.shape[1]
             reps = max(1, min(16, int(2.0e9 // (n_host * D * 4))))
             if W.shape[0] >= 2048:
                 reps = min(reps, 4)
             ctx.set_prototypes(W)
+            if len(made) > 2:
+                ctx.set_omega(made[2])
             X = torch.from_numpy(Xh).cuda().repeat(reps, 1).contiguous()
             N = X.shape[0]
         idx = torch.empty(N, dtype=torch.int32, device="cuda")

@@ -859,15 +859,20 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
     if (finish) {
         const uint32_t slot = m->next_crowd++ % CROWD_SLOTS;
         if (m->crowd_rows[slot] < N) {
-            hipError_t ce = hipDeviceSynchronize();        // (a launch that still uses the old buffer of this slot)
+            // every slot grows at once: one synchronisation (launches that still use the old buffers) and the allocations
+            // in the first call of a size, none in the calls behind it (a caller's warm-up call warms all of it up)
+            hipError_t ce = hipDeviceSynchronize();
             if (ce != hipSuccess) return ce;
-            (void)hipFree(m->crowd[slot]);
-            m->crowd[slot] = nullptr;
-            m->crowd_rows[slot] = 0;
             const uint64_t rows = N + N / 4 + 1024;
-            ce = hipMalloc((void **)&m->crowd[slot], (3 * ((rows + 31) / 32) + 4 + rows) * sizeof(uint32_t));
-            if (ce != hipSuccess) return ce;
-            m->crowd_rows[slot] = rows;
+            for (uint32_t i = 0; i < CROWD_SLOTS; ++i) {
+                if (m->crowd_rows[i] >= rows) continue;
+                (void)hipFree(m->crowd[i]);
+                m->crowd[i] = nullptr;
+                m->crowd_rows[i] = 0;
+                ce = hipMalloc((void **)&m->crowd[i], (3 * ((rows + 31) / 32) + 4 + rows) * sizeof(uint32_t));
+                if (ce != hipSuccess) return ce;
+                m->crowd_rows[i] = rows;
+            }
         }
         cbuf = m->crowd[slot];
         const hipError_t ce = hipMemsetAsync(cbuf, 0, (3 * ntiles32 + 1) * sizeof(uint32_t), s);
