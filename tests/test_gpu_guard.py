@@ -119,6 +119,28 @@ def test_dense_clusters_under_a_global_omega(ctx):
             assert r.hard == 0 and r.dist_fail == 0, f"matching={matching}: {r}"
 
 
+@pytest.mark.parametrize("K,D,copies", [(1024, 128, 40), (256, 128, 40), (4096, 64, 70), (96, 64, 24)], ids=lambda v: str(v))
+def test_a_long_run_of_near_copies(ctx, K, D, copies):
+    """`copies` consecutive prototypes that differ in one low mantissa bit each: every sample near them has more hits in
+    ONE lane of the finish pass than its hit list holds (16 entries in LDS for the streamed engine, 8 registers for the
+    resident kernels), so the lists are drained mid-search and tiles with more than a list's worth are measured on the
+    spot -- and the answer is still the reference's: the closest of the run, lowest index among exact ties."""
+    rng = np.random.default_rng(K * 31 + D + copies)
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    first = K // 3
+    for c in range(1, copies):
+        W[first + c] = W[first]
+        W[first + c, c % D] = np.nextafter(W[first, c % D], np.float32(2.0) if c % 2 else np.float32(-2.0))
+    N = 3001
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    near = rng.integers(0, N, size=N // 2)
+    X[near] = (W[first] + 1e-3 * rng.uniform(-1, 1, size=(len(near), D))).astype(np.float32)
+    X[near[:50]] = W[first]                                               # exact hits on the run's first row
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    _check(ctx, X, W, cls=cls, y=y)
+
+
 @pytest.mark.parametrize("D,K", [(1, 5000), (1, 300), (2, 3000), (3, 4000)], ids=lambda v: str(v))
 def test_many_prototypes_in_few_dimensions(ctx, D, K):
     """Thousands of prototypes on a line / in a plane / in space: dense by counting.  Round 1: scalar kernels."""
