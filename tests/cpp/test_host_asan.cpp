@@ -14,6 +14,7 @@ namespace vq {
 static hipError_t no_device(const EngineArgs &, bool, hipStream_t) { return hipErrorNoDevice; }
 static bool pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
 LaunchFn streamed_launcher(int, int R1, int, int *spb) { *spb = 128; return pow2_in(R1, 16, 256) ? &no_device : nullptr; }
+LaunchFn omega_finish_launcher(int R) { return R == 32 || R == 64 || R == 128 ? &no_device : nullptr; }
 LaunchFn streamed_finish_launcher(int, int R1, int) { return R1 == 64 || R1 == 128 ? &no_device : nullptr; }
 LaunchFn resident_launcher(int R, int *spb) { *spb = 64; return pow2_in(R, 16, 128) ? &no_device : nullptr; }
 LaunchFn resident_pipe_launcher(int R, bool) { return pow2_in(R, 16, 256) ? &no_device : nullptr; }

@@ -45,6 +45,32 @@ def make(case, rng, n_host):
         D, K, M = (128, 256, 128) if case == "random_c3" else (256, 1024, 16)
         Om = (rng.uniform(-1, 1, (M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
         return rng.uniform(-1, 1, (K, D)).astype(np.float32), rng.uniform(-1, 1, (n_host, D)).astype(np.float32), Om
+    if case in ("init_state_omega", "binary_c3", "clustered_c3"):
+        # the Euclidean cases of the same names under a global Omega (k_omega_pipe): the GMLVQ initial state
+        # (src/gmlvq/gmlvq.rs:160-161: Omega = I / sqrt(n)), binary features and dense clusters under a 128 x 128 Omega
+        base = {"init_state_omega": "init_state", "binary_c3": "binary_256", "clustered_c3": "clustered_256"}[case]
+        W, Xh = make(base, rng, n_host)[:2]
+        D = W.shape[1]
+        if case == "init_state_omega":
+            Om = (np.eye(D) / np.sqrt(D)).astype(np.float32)
+        else:
+            Om = np.eye(D) + 0.1 * rng.uniform(-1, 1, (D, D))
+            Om = (Om / np.linalg.norm(Om)).astype(np.float32)
+        return W, Xh, Om
+    if case in ("clustered_c4", "init_state_c4"):
+        # LiRaMLVQ-shaped (k_lowrank_pipe): Omega 16 x D as src/liramlvq/liramlvq.rs:167-171 draws it
+        if case == "clustered_c4":
+            D, K = 256, 1024
+            W, centres = clustered(rng, K, D, 1e-3)
+            pick = rng.integers(0, K, size=n_host)
+            u = rng.normal(size=(n_host, D))
+            u /= np.linalg.norm(u, axis=1, keepdims=True)
+            Xh = (centres[pick] + 3e-3 * np.linalg.norm(centres[pick], axis=1, keepdims=True) * u).astype(np.float32)
+        else:
+            W, Xh = make("init_state", rng, n_host)[:2]
+            D = W.shape[1]
+        Om = rng.uniform(-1, 1, (16, D))
+        return W, Xh, (Om / np.linalg.norm(Om)).astype(np.float32)
     if case == "random_c2":
         return rng.uniform(-1, 1, (256, 128)).astype(np.float32), rng.uniform(-1, 1, (n_host, 128)).astype(np.float32)
     if case == "init_state":
@@ -72,7 +98,7 @@ def make(case, rng, n_host):
     raise SystemExit(f"unknown case {case}")
 
 
-OMEGA_CASES = ["synth_c3", "random_c3", "synth_c4", "random_c4"]
+OMEGA_CASES = ["synth_c3", "random_c3", "init_state_omega", "binary_c3", "clustered_c3", "synth_c4", "random_c4", "init_state_c4", "clustered_c4"]
 CASES = ["synth_c2", "random_c2", "init_state", "clustered_256", "clustered_2048", "binary_256", "random_1024", "random_4096",
          "pixels_784", "pixels_1024"]
 

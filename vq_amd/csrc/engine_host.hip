@@ -493,6 +493,7 @@ bool bind_omega_pipe(EngineModel &m, std::vector<float> &img1, std::vector<float
     m.search_R = R;
     m.search_img = 2;
     m.bfimg_ok = true;
+    if (m.bf && variant_env() == 0 && !getenv("VQHIP_NO_FINISH")) m.finish = omega_finish_launcher(R);
     return true;
 }
 
@@ -754,7 +755,8 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
         }
         // no room for every tile's pieces beside the f32 image: the image becomes the pieces, the exact rows come from L2
         if (m.nbf < res_tiles(m.K) && m.bfimg_ok && !getenv("VQHIP_NO_BFIMG")) {
-            if (m.finish && m.search_img == 1 && !getenv("VQHIP_FINISH_PIECES")) img_f32 = simg;
+            // (the Omega kernels' finish pass has no pieces-image form: it needs the f32 image)
+            if (m.finish && (m.search_img == 2 || !getenv("VQHIP_FINISH_PIECES"))) img_f32 = simg;
             switch (m.search_R) {
             case 16: pieces_image<16>(simg, res_tiles(m.K)); break;
             case 32: pieces_image<32>(simg, res_tiles(m.K)); break;
@@ -891,7 +893,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
             f.list_count = count;
             f.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
             if (m->img_f32) {                                            // the finish pass on the f32 image (hits measured from LDS)
-                f.img1 = m->img_f32;
+                (m->search_img == 2 ? f.img2 : f.img1) = m->img_f32;
                 f.bfimg = 0u;
                 f.imgbf = nullptr;
                 f.nbf = 0u;

@@ -222,9 +222,30 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_lowrank_pipe(const EngineAr
 // per value, one 3 KiB piece per (step of 16 reduction values, tile) -- step-major, so a step's sample pieces are split
 // once, serve every tile and are never stored; two tiles' chains run side by side.  y is at least as exact as from the
 // f32 chain (tools/bf16x6_probe.hip) and everything behind it (search, exact re-measurement) works on that y as before.
-template <int R, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false, bool BFIMG = false, bool PJ = false>
+// FINISH (with BF and CUT, not BFIMG): the finish pass over the samples the first pass marked (crowd_mark, mfma_device.h;
+// k_resident_pipe's FINISH): ids from a.list, rows gathered by id and cut at D, the same projection, then every row
+// within the margin of the running minimum measured exactly from the f32 image in LDS (HitKeys), results scattered.
+template <int R, bool MATCHED, bool CUT = false, int NW = 8, bool BF = false, bool BFIMG = false, bool PJ = false, bool FINISH = false>
 __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs a)
 {
+    static_assert(!FINISH || (BF && CUT && !BFIMG), "the finish pass ranks on the bf16 cores, gathers cut rows and keeps the f32 image");
+    // FINISH: entries of the list; a list of fewer than 32 samples per wave is dealt thin, spb to a wave, one batch each
+    uint32_t count = 0, spb = 32;
+    bool thin = false;
+    if constexpr (FINISH) {
+        count = *a.list_count;
+        if (count > a.N) count = (uint32_t)a.N;       // (never more entries than rows)
+        if (count == 0) return;                        // nothing was marked: not even the image is loaded
+        const uint32_t waves = gridDim.x * NW;
+        if (count < 32u * waves) {
+            thin = true;
+            spb = (count + waves - 1) / waves;         // 1 .. 32
+        }
+    }
+    const uint64_t nbatches = FINISH ? ((uint64_t)count + spb - 1) / spb : a.nbatches;
+    if constexpr (FINISH) {                            // wave w of workgroup g is wave number w * groups + g: see wave_id
+        if ((uint64_t)blockIdx.x * (thin ? 1u : 2u) >= nbatches) return;
+    }
     using Gs = Geom<R>;
     constexpr int NT = R / 32, NJ = R / 8, NSTEP = NT * NJ;   // Omega tiles, reduction steps per tile, pieces
     constexpr int DEPTH = 6;                                  // Omega pieces in flight per wave
@@ -274,13 +295,18 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
 
     // blocks of BLOCK batches per wave: the first fixed, the others claimed a block ahead (BlockQueue)
     constexpr uint32_t BLOCK = 2;
-    BlockQueue<BLOCK> queue(a.queue, lane, blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave), gridDim.x * NW, a.nbatches);
-    uint64_t block0 = (uint64_t)(blockIdx.x * NW + (uint32_t)__builtin_amdgcn_readfirstlane(wave)) * BLOCK;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+    const uint32_t wave_id = FINISH ? wave_u * gridDim.x + blockIdx.x : blockIdx.x * NW + wave_u;
+    BlockQueue<BLOCK> queue(a.queue, lane, wave_id, gridDim.x * NW, nbatches);
+    uint64_t block0 = thin ? (uint64_t)wave_id : (uint64_t)wave_id * BLOCK;   // (thin: batch w is wave w's, the only one)
     uint32_t in_block = 0;                             // position of b inside the current block
-    queue.request();
+    if (!thin) queue.request();
     // the batch after (block0, in_block)
     auto successor = [&](uint64_t &nb0, uint32_t &nin) {
-        if (in_block + 1 < BLOCK) {
+        if (thin) {
+            nb0 = nbatches;
+            nin = 0;
+        } else if (in_block + 1 < BLOCK) {
             nb0 = block0;
             nin = in_block + 1;
         } else {
@@ -291,7 +317,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     const uint32_t row_bytes = a.D * 4u;
     const uint32_t voff = (uint32_t)s_col * row_bytes + (uint32_t)h * 16u;
     f32x4 xn[R / 8];                                   // rows of the next batch, in flight
-    uint32_t ln = 0u;
+    uint32_t ln = 0u, sidn = 0u;                       // its labels; FINISH: its list entries (flags | sample id)
     auto records = [&](uint64_t bb, uint32_t unit) -> uint32_t {
         const uint64_t first = bb * 32;
         if (first >= a.N) return 0u;
@@ -299,6 +325,18 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         return left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left;
     };
     auto fetch = [&](uint64_t bb) {
+        if constexpr (FINISH) {
+            // entry of this lane pair's sample; slots past the list read entry 0 with no flags (searched, never stored)
+            const uint64_t slot = bb * spb + (uint64_t)s_col;
+            uint32_t e = (uint32_t)s_col < spb && slot < count ? a.list[slot] : 0u;
+            if ((e & CROWD_ID) >= a.N) e = 0u;         // (an id that is no row: searched as row 0, never stored)
+            sidn = e;
+            const float *row = a.X + (size_t)(e & CROWD_ID) * a.D;
+#pragma unroll
+            for (int j = 0; j < R / 8; ++j) xn[j] = gather_chunk(row, (uint32_t)(2 * j + h), a.D);
+            if (MATCHED) ln = a.y[e & CROWD_ID];
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rx =
             __builtin_amdgcn_make_buffer_rsrc((void *)(a.X + bb * 32 * a.D), 0, (int)records(bb, row_bytes), 0x00020000);
 #pragma unroll
@@ -318,7 +356,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
     auto lap = [&](int slot) { const unsigned long long t = stamp(); tm[slot] += t - tprev_; tprev_ = t; };
 #endif
 
-    while (block0 < a.nbatches) {                     // the last block may end past nbatches: such a batch reads zeros, stores nothing
+    while (block0 < nbatches) {                       // the last block may end past nbatches: such a batch reads zeros, stores nothing
         uint64_t nb0;
         uint32_t nin;
         successor(nb0, nin);
@@ -331,7 +369,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         // ---- projection y = Omega x: 32 Omega rows per tile, A fragments from the ring; the accumulators of
         //      tile t are chunks 2(4t + g) + h of y, i.e. fragment entries 4t + g of the search stage
         f32x4 yf[R / 8];
-        if constexpr (CUT) {
+        if constexpr (CUT && !FINISH) {                // (gathered rows come in cut: gather_chunk)
 #pragma unroll
             for (int j = 0; j < R / 8; ++j) xn[j] = mask_chunk(xn[j], (uint32_t)(2 * j + h), a.D);
         }
@@ -388,7 +426,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
                 for (int g = 0; g < 4; ++g) yf[4 * t + g] = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
             });
         }
-        const uint32_t label = ln;
+        const uint32_t label = ln, flags = sidn;
 #ifdef VQ_OMEGA_DIAG
         asm volatile("" : "+v"(yf[0][0]), "+v"(yf[R / 8 - 1][3]));
         lap(1);
@@ -396,7 +434,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         // x is dead: the next batch's rows go out now and arrive while this batch is searched.  The atomic
         // goes out after this batch's rows have been waited for (vmcnt counts in issue order).
         asm volatile("" ::: "memory");
-        if (nin == 0) queue.request();
+        if (nin == 0 && !thin) queue.request();
         fetch(bnext);
 
         float ss = 0.0f;
@@ -408,6 +446,33 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         const bool unsafe = !(ss < a.ss_limit);        // NaN / INF / huge: exact scan at the end
         const float margin = unsafe ? 0.0f : screen_margin(ss, a);
 
+        if constexpr (FINISH) {
+            // the searches this sample was marked for; margin +INF: every row is measured (the exact scan)
+            const float mall = (flags & CROWD_ALL) || unsafe ? INFINITY : margin;
+            HitKeys<R, MATCHED, false, 1, 8> hits(yf, img, a.ldp, a.K, flags & (CROWD_P | CROWD_ALL) ? mall : -INFINITY,
+                                                  flags & (CROWD_N | CROWD_ALL) ? mall : -INFINITY);
+            {
+                u32x4 bh[R / 16], bl[R / 16];
+                split_fragment<R>(yf, bh, bl);
+                search_tiles_bf<R>(img, ntiles, label, bh, bl, s_col, h, hits, bfimg, a.nbf);
+            }
+            hits.merge();
+            const uint32_t id = flags & CROWD_ID;
+            if (flags & (CROWD_P | CROWD_ALL)) {
+                if (h == 0) {
+                    if (a.out.idx) a.out.idx[id] = hits.wp.i;
+                } else if (a.out.dist) a.out.dist[id] = hits.wp.d;
+            }
+            if (MATCHED && (flags & (CROWD_N | CROWD_ALL))) {
+                if (h == 0) {
+                    if (a.out.jneg) a.out.jneg[id] = hits.wn.i;
+                } else if (a.out.dneg) a.out.dneg[id] = hits.wn.d;
+            }
+            b = bnext;
+            block0 = nb0;
+            in_block = nin;
+            continue;
+        }
         // ---- search in the projected space (k_resident_pipe's tile loop)
         TopKeys<MATCHED> scr;
         Keys2 &ku = scr.ku;
@@ -427,8 +492,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         lap(2);
 #endif
         Best1 wp, wn;
-        if constexpr (BFIMG) finish_keys_g<R, MATCHED, false>(yf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn);
-        else finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn);
+        if constexpr (BFIMG) finish_keys_g<R, MATCHED, false>(yf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn, a.crowd_mask, b, a.N);
+        else finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn, a.crowd_mask, b, a.N);
         {
             const int rec = (int)records(b, 4u);
             const uint32_t so = (uint32_t)s_col * 4u;
@@ -552,6 +617,38 @@ hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
     return hipGetLastError();
 }
 }  // namespace
+
+namespace {
+// the finish pass of k_omega_pipe: the projection as the first pass ran it (a.pj), the f32 image (a.img2; a.nbf ready tiles)
+template <int R>
+hipError_t launch_omega_finish(const EngineArgs &a, bool matched, hipStream_t st)
+{
+    if (!a.bf || a.bfimg) return hipErrorInvalidValue;
+    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    if (e != hipSuccess) return e;
+    const dim3 grid(256), block(512);
+    if (a.pj) {
+        if (matched)
+            hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true, false, true, true>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((k_omega_pipe<R, false, true, 8, true, false, true, true>), grid, block, 0, st, a);
+    } else if (matched)
+        hipLaunchKernelGGL((k_omega_pipe<R, true, true, 8, true, false, false, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((k_omega_pipe<R, false, true, 8, true, false, false, true>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+LaunchFn omega_finish_launcher(int R)
+{
+    switch (R) {
+    case 32: return &launch_omega_finish<32>;
+    case 64: return &launch_omega_finish<64>;
+    case 128: return &launch_omega_finish<128>;
+    default: return nullptr;
+    }
+}
 
 LaunchFn lowrank_launcher(int R1)
 {

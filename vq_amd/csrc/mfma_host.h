@@ -16,6 +16,7 @@ enum { MODE_EUCLID = 0, MODE_OMEGA = 1, MODE_LOCAL = 2 };
 
 // nullptr when the shape is not instantiated.  samples_per_batch: samples one claimed batch covers.
 LaunchFn streamed_launcher(int mode, int R1, int R2, int *samples_per_batch);    // kernels_engine.hip: k_engine
+LaunchFn omega_finish_launcher(int R);                                            // k_omega_pipe FINISH, or nullptr
 LaunchFn streamed_finish_launcher(int mode, int R1, int R2);                      // k_engine FINISH (the finish pass), or nullptr
 LaunchFn resident_launcher(int R, int *samples_per_batch);                       // kernels_resident.hip: k_resident
 LaunchFn resident_pipe_launcher(int R, bool diag);                               // kernels_resident.hip: k_resident_pipe
