@@ -1751,22 +1751,36 @@ __device__ __forceinline__ void finish_keys_ahead(const f32x4 (&xf)[R / 8], cons
     const float third = pair_third(ku.b1, ku.b2, ku.b3);
     const bool have = key_valid(f) && !unsafe;
     const float fk = __builtin_bit_cast(float, f);
+    // Whether any sample of the wave needs its runner-up measured as well is known from the keys alone.  Then BOTH rows
+    // are requested up front and `between` runs behind their use: a second row requested behind `between`'s loads would
+    // queue behind an HBM round trip (vmcnt completes in order) -- on uniform random data one wave-batch in three.
+    const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - fk > margin);
+    const bool any_close = __builtin_amdgcn_ballot_w64(close) != 0ull;
     f32x4 row[R / 8];
     load_row_g<R>(row, rplain, ldp, have ? fi : 0u, h);
-    asm volatile("" ::: "memory");
-    between();
-    asm volatile("" ::: "memory");
     float d1 = INFINITY;
-    if (have) {
-        d1 = rows_sq<R>(xf, row);
-        if (ROOT) d1 = sqrtf(d1);
-        wp.d = d1; wp.i = fi;
-    }
-    const bool close = have && key_valid(sd) && !(__builtin_bit_cast(float, sd) - fk > margin);
-    if (__builtin_amdgcn_ballot_w64(close) != 0ull) {
-        if (have && key_valid(sd)) {
-            const float d2 = dist(si);
-            if (lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+    if (any_close) {
+        f32x4 row2[R / 8];
+        load_row_g<R>(row2, rplain, ldp, close ? si : 0u, h);           // (lanes that are not close read row 0: one line for all)
+        if (have) {
+            d1 = rows_sq<R>(xf, row);
+            if (ROOT) d1 = sqrtf(d1);
+            wp.d = d1; wp.i = fi;
+        }
+        float d2 = rows_sq<R>(xf, row2);               // (wave-uniform call: the lane pair exchanges halves inside)
+        if (ROOT) d2 = sqrtf(d2);
+        if (close && lexless(d2, si, d1, fi)) { wp.d = d2; wp.i = si; }
+        asm volatile("" ::: "memory");
+        between();
+        asm volatile("" ::: "memory");
+    } else {
+        asm volatile("" ::: "memory");
+        between();
+        asm volatile("" ::: "memory");
+        if (have) {
+            d1 = rows_sq<R>(xf, row);
+            if (ROOT) d1 = sqrtf(d1);
+            wp.d = d1; wp.i = fi;
         }
     }
     // crowded (a third key within the margin), a non-finite winner, or no usable key at all: marked for the finish pass
