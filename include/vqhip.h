@@ -118,7 +118,11 @@ int vqhip_assign_rows_f64(vqhip_ctx *ctx, const double *const *rows, uint64_t N,
                           float *dist_out);
 
 /* Same with device-resident X / outputs, enqueued on `stream` (a hipStream_t; NULL = the
- * default stream) without host synchronisation. */
+ * default stream) without host synchronisation.  Up to three kernels and two small memsets go on the stream: samples
+ * whose ranking the first kernel cannot vouch for (a third candidate within the rounding margin of the best: dense or
+ * duplicated prototypes, binary features, a model in the reference's initial state, src/lvq/lvq.rs:120) are marked, packed
+ * into a list and finished exactly by a second launch; the context keeps 4 B + 12/32 B per row of its
+ * largest call for that, allocated in the first call of a size (which synchronises the device once). */
 int vqhip_assign_device(vqhip_ctx *ctx, const float *dX, uint64_t N, uint32_t *didx_out,
                         float *ddist_out, void *stream);
 
@@ -136,7 +140,9 @@ int vqhip_prepare(vqhip_ctx *ctx);
  *     mfma_omega_two_pass); for the others VQHIP_ERR_UNSUPPORTED (their scratch grows with N)
  *   - N <= VQHIP_NOALLOC_MAX_ROWS, VQHIP_ERR_INVALID beyond (the counters are 32-bit)
  *   - every call on one GPU shares that GPU's counters: calls that overlap on one GPU (two streams, two contexts,
- *     two threads) race.  Order them on one stream or use vqhip_assign_device. */
+ *     two threads) race.  Order them on one stream or use vqhip_assign_device.
+ *   - one launch, no finish pass (its list would have to be allocated): samples the ranking cannot settle are scanned
+ *     exactly inside their wave, as in round 2 -- same results, slower on the inputs DESIGN.md 4.12 lists. */
 #define VQHIP_NOALLOC_MAX_ROWS (1ull << 36)
 int vqhip_assign_device_noalloc(vqhip_ctx *ctx, const float *dX, uint64_t N, uint32_t *didx_out,
                                 float *ddist_out, void *stream);
