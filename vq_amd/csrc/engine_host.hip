@@ -788,6 +788,11 @@ EngineModel *engine_build(const std::vector<float> &Win, uint32_t K, uint32_t D,
     return out;
 }
 
+hipError_t zero_queue(const EngineArgs &a, hipStream_t st)
+{
+    return a.queue_zeroed ? hipSuccess : hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+}
+
 void engine_free(EngineModel *m)
 {
     if (!m) return;
@@ -842,6 +847,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
         if (dbg_buf) (void)hipMemsetAsync(dbg_buf, 0, 256, s);
     }
     a.queue = queue ? queue : m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
+    a.queue_zeroed = 0u;
     a.mu = m->mu;
     a.mscale = m->mscale;
     a.bf = m->bf ? 1u : 0u;
@@ -871,15 +877,21 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
                 (void)hipFree(m->crowd[i]);
                 m->crowd[i] = nullptr;
                 m->crowd_rows[i] = 0;
-                ce = hipMalloc((void **)&m->crowd[i], (3 * ((rows + 31) / 32) + 4 + rows) * sizeof(uint32_t));
+                ce = hipMalloc((void **)&m->crowd[i], (2 * (size_t)QUEUE_STRIDE + 3 * ((rows + 31) / 32) + 4 + rows) * sizeof(uint32_t));
                 if (ce != hipSuccess) return ce;
                 m->crowd_rows[i] = rows;
             }
         }
-        cbuf = m->crowd[slot];
-        const hipError_t ce = hipMemsetAsync(cbuf, 0, (3 * ntiles32 + 1) * sizeof(uint32_t), s);
+        // the slot: [batch counters of the first pass][of the finish pass][3 mask words per tile][count, 3 pad][list] --
+        // counters, marks and count zeroed by ONE memset (three separate ones and the launches they sit between cost a
+        // small call 10 us: tools/small_batch_bench.py)
+        uint32_t *const slot_base = m->crowd[slot];
+        cbuf = slot_base + 2 * (size_t)QUEUE_STRIDE;
+        const hipError_t ce = hipMemsetAsync(slot_base, 0, (2 * (size_t)QUEUE_STRIDE + 3 * ntiles32 + 1) * sizeof(uint32_t), s);
         if (ce != hipSuccess) return ce;
         a.crowd_mask = cbuf;
+        a.queue = slot_base;
+        a.queue_zeroed = 1u;
     }
     hipError_t e = m->launch(a, dy != nullptr, s);
     if (finish && e == hipSuccess) {
@@ -891,7 +903,7 @@ hipError_t engine_assign(const EngineModel *m, const float *dX, uint64_t N, cons
             f.crowd_mask = nullptr;
             f.list = list;
             f.list_count = count;
-            f.queue = m->queue + (m->next_slot++ % QUEUE_SLOTS) * QUEUE_STRIDE;
+            f.queue = a.queue + QUEUE_STRIDE;                            // (zeroed with the marks)
             if (m->img_f32) {                                            // the finish pass on the f32 image (hits measured from LDS)
                 (m->search_img == 2 ? f.img2 : f.img1) = m->img_f32;
                 f.bfimg = 0u;

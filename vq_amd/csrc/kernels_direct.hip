@@ -185,7 +185,7 @@ hipError_t launch_direct(const EngineArgs &a, bool matched, hipStream_t st)
     constexpr int NW = 8;                                             // waves per workgroup = per CU: 2 per SIMD
     const uint64_t wgs = (a.nbatches + NW - 1) / NW;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);          // one workgroup per CU
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     const bool cut = a.D < (uint32_t)R;
     if (matched && cut)

@@ -467,7 +467,7 @@ hipError_t launch_t(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t cap = 256ull * WPS;                                // 256 CUs x workgroups per CU
     const unsigned grid = (unsigned)(a.nbatches < cap ? a.nbatches : cap);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if constexpr (MODE != MODE_LOCAL && (MODE == MODE_OMEGA ? R2 : R1) <= 128) {
         // Group keys where a candidate's four rows are one or two fetches each (the exact rows come from L2 here, a round
@@ -502,7 +502,7 @@ template <int MODE, int R1, int R2, int S, int WPS = (R1 >= 256 ? 1 : 2)>
 hipError_t launch_finish_t(const EngineArgs &a, bool matched, hipStream_t st)
 {
     if constexpr (MODE != MODE_LOCAL && (MODE == MODE_OMEGA ? R2 : R1) <= 128) {
-        const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+        const hipError_t e = zero_queue(a, st);
         if (e != hipSuccess) return e;
         const unsigned grid = 256u * WPS;
         if (matched)

@@ -207,7 +207,7 @@ template <int R1, int S, int NW = 4>
 hipError_t launch_local_pj(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const unsigned grid = (unsigned)(a.nbatches < 256 ? a.nbatches : 256);      // one workgroup per CU
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_local_pj<R1, S, true, NW>), dim3(grid), dim3(NW * 64), 0, st, a);

@@ -598,7 +598,7 @@ hipError_t launch_long(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_long<NT, true>), dim3(grid), dim3(512), 0, st, a);
@@ -614,7 +614,7 @@ hipError_t launch_omega_long(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_omega_long<R2, true>), dim3(grid), dim3(512), 0, st, a);
@@ -640,7 +640,7 @@ hipError_t launch_local_long(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if (matched)
         hipLaunchKernelGGL((k_local_long<NT, true>), dim3(grid), dim3(512), 0, st, a);

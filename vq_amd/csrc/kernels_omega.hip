@@ -533,7 +533,7 @@ hipError_t launch_lowrank(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if (a.bf) {
         if (a.D < (uint32_t)R1) {
@@ -562,7 +562,7 @@ hipError_t launch_omega_pipe(const EngineArgs &a, bool matched, hipStream_t st)
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if (a.pj && !a.bf) return hipErrorInvalidValue;                     // built together (bind_omega_pipe)
     if (a.pj && a.bfimg) {
@@ -624,7 +624,7 @@ template <int R>
 hipError_t launch_omega_finish(const EngineArgs &a, bool matched, hipStream_t st)
 {
     if (!a.bf || a.bfimg) return hipErrorInvalidValue;
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     const dim3 grid(256), block(512);
     if (a.pj) {

@@ -509,7 +509,7 @@ hipError_t launch_resident_staged(const EngineArgs &a, bool matched, hipStream_t
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if (R == 128 && a.dbg && !matched)                               // diagnostic build (VQHIP_VARIANT=32): phase stamps
         hipLaunchKernelGGL((k_resident_pipe<128, false, true, 8, true>), dim3(grid), dim3(512), 0, st, a);
@@ -529,7 +529,7 @@ hipError_t launch_resident_cut(const EngineArgs &a, bool matched, hipStream_t st
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if constexpr (R <= 128) {
         if (a.bf && a.bfimg) {
@@ -559,7 +559,7 @@ hipError_t launch_resident_pipe(const EngineArgs &a, bool matched, hipStream_t s
 {
     const uint64_t wgs = (a.nbatches + 7) / 8;
     const unsigned grid = (unsigned)(wgs < 256 ? wgs : 256);
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     if constexpr (R <= 128 && !DIAG) {
         if (a.bf) {
@@ -605,7 +605,7 @@ namespace {
 template <int R>
 hipError_t launch_resident_finish(const EngineArgs &a, bool matched, hipStream_t st)
 {
-    const hipError_t e = hipMemsetAsync(a.queue, 0, QUEUE_BYTES, st);
+    const hipError_t e = zero_queue(a, st);
     if (e != hipSuccess) return e;
     const dim3 grid(256), block(512);
     if (a.bfimg) {

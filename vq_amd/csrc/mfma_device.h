@@ -43,6 +43,7 @@ struct EngineArgs {
     uint32_t bfimg;           // the search image itself holds bf16 pieces (every tile); exact rows come from `plain`
     uint32_t pj;              // Omega kernels: img1 holds Omega as three bf16 pieces per value, the projection runs on the bf16 matrix cores
     uint32_t *queue;          // k_engine: batch counter, zeroed before every launch
+    uint32_t queue_zeroed;    // the caller's memset has covered the counters already (zero_queue, mfma_host.h)
     const uint32_t *cls;      // K class ids (labelled models)
     unsigned long long *dbg;  // diagnostic build of k_resident_pipe: per-wave cycle sums of the loop phases
     // Samples the screening cannot settle (crowd_mark below).  First pass: crowd_mask = three bit planes per tile of 32

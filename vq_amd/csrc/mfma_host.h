@@ -38,6 +38,9 @@ LaunchFn local_pj_launcher(int R1, int *samples_per_batch);
 constexpr uint32_t QUEUE_GROUPS = 16;
 constexpr uint32_t QUEUE_GROUP_STRIDE = 1024;                                    // in u32
 constexpr size_t QUEUE_BYTES = (size_t)QUEUE_GROUPS * QUEUE_GROUP_STRIDE * sizeof(uint32_t);
+// a launch's batch counters start at zero: by this memset, or by one the caller has issued over a buffer that holds them
+// (engine_assign: counters of both passes and the marks in one piece, one memset instead of three)
+hipError_t zero_queue(const EngineArgs &a, hipStream_t st);      // (engine_host.hip)
 
 constexpr int RES_BYTES = 156 * 1024;       // LDS one resident workgroup may fill with images
 constexpr float PAD_SCORE = 3.0e38f;        // accumulator init of pad rows: finite, above every real score
