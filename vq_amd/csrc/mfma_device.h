@@ -57,8 +57,16 @@ struct EngineArgs {
 namespace {
 
 // ------------------------------------------------------------------------------ small helpers
-__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
-__device__ __forceinline__ uint32_t xor32(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 32, 64); }
+// The value of lane ^ 32 (the other lane of a sample's pair).  v_permlane32_swap_b32 (gfx950) swaps the upper half of one
+// register with the lower half of another: of two copies of v one ends up holding the lower half twice, the other the
+// upper half twice -- two vector instructions and no trip through the LDS queue (ds_bpermute_b32: the epilogues' twelve
+// exchanges per batch each waited for it).
+__device__ __forceinline__ uint32_t xor32(uint32_t v)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0]: v of lanes 0..31 in both halves, r[1]: of 32..63
+    return (threadIdx.x & 32u) ? (uint32_t)r[0] : (uint32_t)r[1];
+}
+__device__ __forceinline__ float xor32(float v) { return __builtin_bit_cast(float, xor32(__builtin_bit_cast(uint32_t, v))); }
 
 __device__ __forceinline__ bool lexless(float av, uint32_t ai, float bv, uint32_t bi)
 {
