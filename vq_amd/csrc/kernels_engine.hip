@@ -276,6 +276,16 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
         HitKeys<RS, MATCHED, ROOT, 2, HIT_CAP> hits1(yf[S - 1], a.plain, a.ldp, a.K, hit_margin(S - 1, CROWD_P), hit_margin(S - 1, CROWD_N),
                                                      hit_lds + (FINISH ? (S - 1) * 2 * HIT_CAP * 256 + tid : 0), 256u);
         static_assert(S <= 2, "one HitKeys per sample tile of the wave");
+        // One sample tile per wave, unlabelled, on the bf16 cores: the scores of a tile are screened between the MFMAs of
+        // the next one (tile_mma_ready_spread); the last tile's after the stage loop.
+        constexpr bool SPREAD = BF && !GRP && !FINISH && !MATCHED && S == 1 && RS >= 96 && MODE == MODE_EUCLID;
+        TopKeys<false> spread_scr;
+        f32x16 held;                                                  // SPREAD: the finished scores of the tile before
+        uint32_t held_id = 0u;
+        if constexpr (SPREAD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) held[r] = PAD_SCORE;         // "tile -1": its keys never win
+        }
         const uint32_t nsearch = MODE == MODE_OMEGA ? a.ngroups2 : a.ngroups1;
         for (uint32_t qs = 0; qs < nsearch; ++qs) {
             step([&](const float *stage) {
@@ -311,9 +321,17 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
                     for (int tt = 0; tt < G2::G; ++tt) {
                         const float *tile = stage + tt * G2::TILE_FLOATS;
                         f32x16 acc[S];
+                        const uint32_t tile_id = qs * G2::G + tt;
+                        if constexpr (SPREAD) {
+                            spread_scr.ku = ku[0];
+                            tile_mma_ready_spread<RS>(tile, bh[0], bl[0], acc[0], held, held_id, spread_scr, s_col, h);
+                            ku[0] = spread_scr.ku;
+                            held = acc[0];
+                            held_id = tile_id;
+                            continue;
+                        }
                         if constexpr (BF) tile_mma_ready<RS, S>(tile, bh, bl, acc, s_col, h);   // (the stage holds pieces: engine_build)
                         else tile_mma<RS, S>(tile, yf, acc, s_col, h);
-                        const uint32_t tile_id = qs * G2::G + tt;
                         const uint32_t *tcls = (const uint32_t *)(tile + G2::W_FLOATS) + 32 + 4 * h;
                         Keys2 ou[S];
                         KeysM om[S];
@@ -363,6 +381,11 @@ __global__ void __launch_bounds__(256, WPS) k_engine(const EngineArgs a)
             });
         }
 
+        if constexpr (SPREAD) {                                       // the last tile's scores
+            const Keys2 before = ku[0];
+            screen16<1>(held, ku[0]);
+            settle_tiles(ku[0], before, held_id);
+        }
         // ---- epilogue: lane pair (s, h=0/1) agrees on the candidates, re-measures them exactly, stores
         if constexpr (FINISH) {
             hits0.merge();

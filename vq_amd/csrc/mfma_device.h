@@ -980,6 +980,46 @@ __device__ __forceinline__ void tile_mma_ready(const float *tile, const u32x4 (&
     }
 }
 
+// tile_mma_ready for one sample tile with the screening of the PREVIOUS tile's scores between its MFMAs (pieces_step's
+// interleave for the streamed engine): score o of `prev` behind MFMA o + 1 of this tile, pinned there.  `prev` comes in
+// finished (its last MFMA was the last one of the previous call, or it is the pad tile) and is not written here.
+template <int R, class SCR>
+__device__ __forceinline__ void tile_mma_ready_spread(const float *tile, const u32x4 (&bh)[R / 16], const u32x4 (&bl)[R / 16], f32x16 &acc,
+                                                      f32x16 &prev, uint32_t tprev_id, SCR &scr, int row, int h)
+{
+    using Gm = Geom<R>;
+    constexpr int NQ = R / 16;
+    static_assert(NQ >= 6, "16 scores need 17 MFMAs of the tile");
+    const float *tail = tile + Gm::W_FLOATS;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ci = *(const f32x4 *)(tail + 8 * g + 4 * h);
+        acc[4 * g + 0] = ci[0]; acc[4 * g + 1] = ci[1]; acc[4 * g + 2] = ci[2]; acc[4 * g + 3] = ci[3];
+    }
+    const char *rowp = (const char *)tile + row * (Gm::ROW_FLOATS * 4) + 32 * h;
+    static_for<0, NQ>([&](auto qq) {
+        constexpr int q = decltype(qq)::value;
+        const bf16x8 vah = __builtin_bit_cast(bf16x8, *(const u32x4 *)(rowp + 64 * q));
+        const bf16x8 val = __builtin_bit_cast(bf16x8, *(const u32x4 *)(rowp + 64 * q + 16));
+        auto slot = [&](auto ii) {
+            constexpr int sidx = 3 * q + decltype(ii)::value;           // MFMA number in the tile
+            if constexpr (sidx >= 1 && sidx <= 16) {
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (sidx == 1) scr.begin();
+                scr.template one<sidx - 1, (sidx == 1 ? 1 : 0)>(prev, nullptr, 0u, h);
+                if constexpr (sidx == 16) scr.end(tprev_id);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(val, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+        slot(std::integral_constant<int, 0>{});
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, __builtin_bit_cast(bf16x8, bl[q]), acc, 0, 0, 0);
+        slot(std::integral_constant<int, 1>{});
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vah, __builtin_bit_cast(bf16x8, bh[q]), acc, 0, 0, 0);
+        slot(std::integral_constant<int, 2>{});
+    });
+}
+
 // Bytes of one tile of bf16 pieces (host: build_bf_tiles): the rows of the f32 tile at the same pitch, each row holding,
 // per reduction step q and lane half h, the 8 hi pieces and then the 8 lo pieces of that lane's values (16 + 16 bytes).
 template <int R>
