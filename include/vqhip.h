@@ -118,11 +118,12 @@ int vqhip_assign_rows_f64(vqhip_ctx *ctx, const double *const *rows, uint64_t N,
                           float *dist_out);
 
 /* Same with device-resident X / outputs, enqueued on `stream` (a hipStream_t; NULL = the
- * default stream) without host synchronisation.  Up to three kernels and two small memsets go on the stream: samples
+ * default stream) without host synchronisation.  Up to three kernels and one memset go on the stream: samples
  * whose ranking the first kernel cannot vouch for (a third candidate within the rounding margin of the best: dense or
  * duplicated prototypes, binary features, a model in the reference's initial state, src/lvq/lvq.rs:120) are marked, packed
- * into a list and finished exactly by a second launch; the context keeps 4 B + 12/32 B per row of its
- * largest call for that, allocated in the first call of a size (which synchronises the device once). */
+ * into a list and finished exactly by a second launch; the context keeps about 22 B per row of its
+ * largest call for that (four round-robin slots of marks and list), allocated in the first call of a size (which
+ * synchronises the device once). */
 int vqhip_assign_device(vqhip_ctx *ctx, const float *dX, uint64_t N, uint32_t *didx_out,
                         float *ddist_out, void *stream);
 
