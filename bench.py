@@ -533,8 +533,12 @@ def run_rank(args):
                              "flops over the matrix cores' least time for its instruction mix (3 bf16 products per search product, 6 per "
                              "projection product, f32 at 157.3); cpu_* = f64 C oracle on bounded samples (DESIGN.md 5)")
             # last key: the driver keeps the tail of the line
-            line["extra_summary"] = {k: [e["value"], e["frac"], e["bound"]] for k, e in line["extra"].items()}
-            line["extra_summary"][line["config"]["name"]] = [line["value"], line["roofline"]["frac"], line["roofline"]["bound"]]
+            # [samples/s, fraction of the roofline named next, that roofline (hbm | mfma), what the counters say binds]
+            short = {"valu-issue + epilogue latency": "valu-issue", "hbm stream": "hbm", "mfma": "mfma"}
+            line["extra_summary"] = {k: [e["value"], e["frac"], e["bound"], short.get(e.get("limiter"), e.get("limiter"))]
+                                     for k, e in line["extra"].items()}
+            line["extra_summary"][line["config"]["name"]] = [line["value"], line["roofline"]["frac"], line["roofline"]["bound"],
+                                                             short.get(line["roofline"]["limiter"], line["roofline"]["limiter"])]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(sig4(line)) + "\n").encode())
     if gather:
