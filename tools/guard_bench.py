@@ -80,6 +80,13 @@ def make(case, rng, n_host):
         W = np.concatenate([means[c] + rng.uniform(-0.1, 0.1, size=(per, 1)) for c in range(classes)]).astype(np.float32)
         X = (means[rng.integers(0, classes, size=n_host)] + 0.3 * rng.uniform(-1, 1, size=(n_host, D))).astype(np.float32)
         return W, X
+    if case == "init_state_784":
+        # the reference's initial state on pixel-like rows: 10 classes x 3 prototypes on a line +-0.1 around class means in [0, 1)
+        D, classes, per = 784, 10, 3
+        means = rng.uniform(0, 1, size=(classes, D))
+        W = np.concatenate([means[c] + rng.uniform(-0.1, 0.1, size=(per, 1)) for c in range(classes)]).astype(np.float32)
+        X = np.clip(means[rng.integers(0, classes, size=n_host)] + 0.3 * rng.uniform(-1, 1, size=(n_host, D)), 0, 1).astype(np.float32)
+        return W, X
     if case.startswith("clustered_"):
         K, D = int(case.split("_")[1]), 128
         W, centres = clustered(rng, K, D, 1e-3)
@@ -101,7 +108,7 @@ def make(case, rng, n_host):
 
 OMEGA_CASES = ["synth_c3", "random_c3", "init_state_omega", "binary_c3", "clustered_c3", "synth_c4", "random_c4", "init_state_c4", "clustered_c4"]
 CASES = ["synth_c2", "random_c2", "init_state", "clustered_256", "clustered_2048", "binary_256", "random_1024", "random_4096",
-         "pixels_784", "pixels_1024"]
+         "pixels_784", "pixels_1024", "init_state_784"]
 
 
 def main():
