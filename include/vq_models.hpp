@@ -304,15 +304,17 @@ protected:
         upload();
         const size_t N = data.size(), D = dim();
         const size_t width = which == VQHIP_PROJECT_OMEGA ? omega_.rows : D;
-        std::vector<float> X(N * D), Y(N * width);
+        // the reference's container on both sides: the library gathers / narrows and widens / scatters in its pinned
+        // buffers (vqhip_project_rows_f64), no contiguous copy of either matrix here
+        Data out(N, Vector(width));
+        std::vector<const double *> rows(N);
+        std::vector<double *> out_rows(N);
         for (size_t i = 0; i < N; ++i) {
             rust_assert(data[i].size() == D, "assertion failed: vec1.len() == vec2.len()");
-            for (size_t d = 0; d < D; ++d) X[i * D + d] = (float)data[i][d];
+            rows[i] = data[i].data();
+            out_rows[i] = out[i].data();
         }
-        dev_->check(vqhip_project(dev_->get(), X.data(), N, which, Y.data()));
-        Data out(N, Vector(width));
-        for (size_t i = 0; i < N; ++i)
-            for (size_t d = 0; d < width; ++d) out[i][d] = Y[i * width + d];
+        dev_->check(vqhip_project_rows_f64(dev_->get(), rows.data(), N, (uint32_t)D, which, out_rows.data()));
         return out;
     }
 

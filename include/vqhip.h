@@ -238,6 +238,11 @@ int vqhip_multi_assign_device(vqhip_multi *m, const float *const *dX, const uint
 typedef enum { VQHIP_PROJECT_OMEGA = 0, VQHIP_PROJECT_LAMBDA = 1 } vqhip_projection;
 int vqhip_project(vqhip_ctx *ctx, const float *X, uint64_t N, int which /* vqhip_projection */, float *Y);
 int vqhip_project_device(vqhip_ctx *ctx, const float *dX, uint64_t N, int which, float *dY, void *stream);
+/* The same for the reference's container on both sides (`data: &Vec<Array1<f64>>` in, `Vec<Array1<f64>>` out:
+ * src/gmlvq/gmlvq.rs:354-372): rows[i] points at D doubles, out_rows[i] at room for the projected row (M doubles for
+ * VQHIP_PROJECT_OMEGA, D for VQHIP_PROJECT_LAMBDA).  Rows are gathered and narrowed into the pinned upload buffers and the
+ * results widened straight out of the pinned download buffers by the host cores, overlapped with the transfers. */
+int vqhip_project_rows_f64(vqhip_ctx *ctx, const double *const *rows, uint64_t N, uint32_t D, int which, double *const *out_rows);
 
 /* ---- the Euclidean path in the reference's own number type ------------
  * euclidean_distance + find_closest_prototype{,_matched} in f64 (src/helpers.rs:11-24, 55-77, 91-132):

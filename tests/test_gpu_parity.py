@@ -454,6 +454,29 @@ def _rel_err(got, want):
     return float((np.abs(got - want) / scale).max())
 
 
+def test_project_rows_f64_equals_contiguous_f32(ctx):
+    """vqhip_project_rows_f64 (the reference's container in and out, src/gmlvq/gmlvq.rs:354-372): the rows of vqhip_project on
+    the same values, widened; more rows than one pinned chunk holds, project and project_omega, ragged input refused."""
+    from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA
+    rng = np.random.default_rng(77)
+    D, M, K = 96, 12, 40
+    N = (128 << 20) // (D * 4) + 1234                                       # two chunks of the pinned pipeline
+    W = rng.uniform(-1, 1, size=(K, D)).astype(np.float32)
+    Om = (rng.uniform(-1, 1, size=(M, D)) / np.sqrt(M * D / 3.0)).astype(np.float32)
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    ctx.set_prototypes(W)
+    ctx.set_omega(Om)
+    rows = [np.array(r, dtype=np.float64) for r in X]                        # one allocation per row
+    for which, width in ((PROJECT_LAMBDA, D), (PROJECT_OMEGA, M)):
+        want = ctx.project(X, which)
+        got = ctx.project_rows(rows, which)
+        assert len(got) == N and all(g.shape == (width,) for g in got[:5])
+        assert np.array_equal(np.stack(got).astype(np.float32), want), which
+    assert ctx.project_rows([], PROJECT_OMEGA) == []
+    with pytest.raises(ValueError):
+        ctx.project_rows([np.zeros(D), np.zeros(D - 1)])                   # ragged row (src/helpers.rs:14)
+
+
 @pytest.mark.parametrize("shape", [s for s in SHAPES if s[6] == "global"], ids=lambda s: s[0])
 def test_project_global(ctx, shape):
     from vq_amd import PROJECT_LAMBDA, PROJECT_OMEGA

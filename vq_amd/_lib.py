@@ -30,6 +30,7 @@ SIGNATURES = {
     "vqhip_assign_rows_f64": (C.c_int, [_v, C.POINTER(C.POINTER(C.c_double)), C.c_uint64, C.c_uint32, _u, _f]),
     "vqhip_project": (C.c_int, [_v, _f, C.c_uint64, C.c_int, _f]),
     "vqhip_project_device": (C.c_int, [_v, _v, C.c_uint64, C.c_int, _v, _v]),
+    "vqhip_project_rows_f64": (C.c_int, [_v, _v, C.c_uint64, C.c_uint32, C.c_int, _v]),
     "vqhip_set_prototypes_f64": (C.c_int, [_v, C.POINTER(C.c_double), C.c_uint32, C.c_uint32]),
     "vqhip_assign_f64": (C.c_int, [_v, C.POINTER(C.c_double), C.c_uint64, _u, C.POINTER(C.c_double)]),
     "vqhip_assign_matched_f64": (C.c_int, [_v, C.POINTER(C.c_double), _u, C.c_uint64, _u, C.POINTER(C.c_double), _u,

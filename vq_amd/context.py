@@ -151,6 +151,21 @@ class Context:
         self._chk(self._L.vqhip_project(self._h, _fp(X), X.shape[0], int(which), _fp(Y)))
         return Y
 
+    def project_rows(self, rows, which: int = _lib.PROJECT_LAMBDA):
+        """project / project_omega for the reference's container on both sides: separately allocated f64 rows in, a list of
+        separately allocated f64 rows out (src/gmlvq/gmlvq.rs:354-372)."""
+        rows = [np.ascontiguousarray(r, dtype=np.float64) for r in rows]
+        N = len(rows)
+        for r in rows:
+            if r.ndim != 1 or r.shape[0] != self.D:
+                raise ValueError(f"every row must hold {self.D} values")
+        width = self.M if which == _lib.PROJECT_OMEGA else self.D
+        out = [np.empty(width, dtype=np.float64) for _ in range(N)]
+        ptrs = (C.POINTER(C.c_double) * max(N, 1))(*[r.ctypes.data_as(C.POINTER(C.c_double)) for r in rows])
+        optrs = (C.POINTER(C.c_double) * max(N, 1))(*[r.ctypes.data_as(C.POINTER(C.c_double)) for r in out])
+        self._chk(self._L.vqhip_project_rows_f64(self._h, ptrs, N, self.D, int(which), optrs))
+        return out
+
     # -- the Euclidean path in f64 (bit-exact against the reference's arithmetic)
     def set_prototypes_f64(self, W):
         W = np.ascontiguousarray(W, dtype=np.float64)

@@ -781,7 +781,10 @@ int run_host_f64(vqhip_ctx *c, const double *X, const uint32_t *y, uint64_t N, u
 
 // project / project_omega from host pointers: the pinned, double-buffered pipeline of run_host (pack | H2D | kernel |
 // D2H | unpack on two streams), the projected rows in place of the winners.
-int run_host_project(vqhip_ctx *c, const float *X, uint64_t N, int which, float *Y)
+// where the projected rows of a chunk go: (pinned source, first row, rows, width)
+using Unpacker = std::function<void(const float *, uint64_t, uint64_t, uint32_t)>;
+
+int run_host_project(vqhip_ctx *c, const Packer &pack, uint64_t N, int which, const Unpacker &unpack)
 {
     int rc = check_project(c, which);
     if (rc != VQHIP_OK || N == 0) return rc;
@@ -800,15 +803,12 @@ int run_host_project(vqhip_ctx *c, const float *X, uint64_t N, int which, float 
             HIPCHK(c, hipMalloc((void **)&s.dP, chunk * Wd * sizeof(float)));
             s.p_cap = chunk * Wd;
         }
-    const Packer pack = contiguous_f32(c, X);
     const uint64_t nchunks = (N + chunk - 1) / chunk;
     auto finish = [&](uint64_t ci) -> int {
         Staging &s = c->st[ci & 1];
         HIPCHK(c, hipStreamSynchronize(s.stream));
         const uint64_t off = ci * chunk, n = std::min<uint64_t>(chunk, N - off);
-        const float *src = s.hP;
-        float *dst = Y + off * Wd;
-        parallel_rows(n, [=](uint64_t a, uint64_t b) { std::memcpy(dst + a * Wd, src + a * Wd, (b - a) * Wd * sizeof(float)); });
+        unpack(s.hP, off, n, Wd);
         return VQHIP_OK;
     };
     for (uint64_t ci = 0; ci < nchunks; ++ci) {
@@ -1189,7 +1189,32 @@ try {
     if (!c) return VQHIP_ERR_INVALID;
     if (N && (!X || !Y)) return c->fail(VQHIP_ERR_INVALID, "project: X or Y is NULL");
     HIPCHK(c, hipSetDevice(c->device));
-    return run_host_project(c, X, N, which, Y);
+    return run_host_project(c, contiguous_f32(c, X), N, which, [Y](const float *src, uint64_t first, uint64_t n, uint32_t Wd) {
+        float *dst = Y + first * Wd;
+        parallel_rows(n, [=](uint64_t a, uint64_t b) { std::memcpy(dst + a * Wd, src + a * Wd, (b - a) * Wd * sizeof(float)); });
+    });
+}
+VQHIP_CATCH(c)
+
+int vqhip_project_rows_f64(vqhip_ctx *c, const double *const *rows, uint64_t N, uint32_t D, int which, double *const *out_rows)
+try {
+    if (!c) return VQHIP_ERR_INVALID;
+    if (N && (!rows || !out_rows)) return c->fail(VQHIP_ERR_INVALID, "project_rows_f64: rows or out_rows is NULL");
+    if (c->K && D != c->D) return c->fail(VQHIP_ERR_INVALID, "project_rows_f64: D differs from the prototypes");
+    for (uint64_t i = 0; i < N; ++i)
+        if (!rows[i] || !out_rows[i]) return c->fail(VQHIP_ERR_INVALID, "project_rows_f64: a row pointer is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    // gathered and narrowed into the pinned upload buffers, widened straight out of the pinned download buffers: no
+    // contiguous copy of either matrix on the host
+    return run_host_project(c, rows_f64(rows, D), N, which, [out_rows](const float *src, uint64_t first, uint64_t n, uint32_t Wd) {
+        parallel_rows(n, [=](uint64_t a, uint64_t b) {
+            for (uint64_t i = a; i < b; ++i) {
+                double *dst = out_rows[first + i];
+                const float *r = src + i * Wd;
+                for (uint32_t d = 0; d < Wd; ++d) dst[d] = (double)r[d];
+            }
+        });
+    });
 }
 VQHIP_CATCH(c)
 
