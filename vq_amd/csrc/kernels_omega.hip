@@ -480,6 +480,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         if constexpr (BF) {        // the ranking on the bf16 matrix cores (search_tiles_bf); the projection above: f32, or bf16x6 with PJ
             u32x4 bh[R / 16], bl[R / 16];
             split_fragment<R>(yf, bh, bl);
+            __builtin_amdgcn_s_setprio(0);             // (k_resident_pipe: the wave outside its tile loop goes first)
             if constexpr (BFIMG)
                 search_pieces<R>((const char *)img, (uint32_t)Gs::TILE_BYTES, img + Gs::W_FLOATS, ntiles, label, bh, bl, s_col, h, scr);
             else
@@ -492,6 +493,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) k_omega_pipe(const EngineArgs
         lap(2);
 #endif
         Best1 wp, wn;
+        if constexpr (BF) __builtin_amdgcn_s_setprio(3);
         if constexpr (BFIMG) finish_keys_g<R, MATCHED, false>(yf, a.plain, a.ldp, a.cls, a.K, label, h, unsafe, margin, ku, km, wp, wn, a.crowd_mask, b, a.N);
         else finish_keys<R, MATCHED, false>(yf, img, a.K, label, h, unsafe, margin, ku, km, wp, wn, a.crowd_mask, b, a.N);
         {
