@@ -1270,6 +1270,7 @@ template <int R, bool MATCHED, bool ROOT, int ROWS, int CAP = 0>
 struct HitKeys {
     static_assert(CAP == 0 || CAP == 8 || CAP == 16, "0: on the spot, 8: register list, 16: LDS list");
     uint32_t ids[CAP == 8 ? 8 : 1] = {};   // CAP == 8: the list (row | side << 31)
+    float listed_at = INFINITY;            // CAP == 8: the running minimum when the list last grew (no entry scores below it)
     static constexpr bool SPREAD = false;
     __device__ __forceinline__ void begin() {}                       // (the spread form is TopKeys' alone)
     template <int O, int PRE>
@@ -1311,9 +1312,32 @@ struct HitKeys {
             else wn.offer(d, mine);
         }
     }
-    // the listed hits, oldest first (index order inside a lane), against the thresholds as they stand now
+    // The list against the thresholds as they stand NOW: an entry whose score lies above the running minimum + margin of
+    // this moment can never qualify (the minimum only falls) and leaves; the others move up, order kept (index order inside
+    // a lane: strict '<').  What it buys: the steps of a drain are the busiest lane's entries, and before the sample's
+    // true neighbourhood turns up every tile with a new running minimum lists a row -- different lanes hold their live
+    // entries at different places of the list, so without the closing-up nearly every place is some lane's.
+    __device__ __forceinline__ void filter()
+    {
+        if constexpr (CAP == 16) {               // (the register list keeps no scores: tile() has its own, coarser rule)
+            const float thr_p = run_p + margin_p, thr_n = run_n + margin_n;
+            uint32_t w = 0u;
+            for (uint32_t i = 0; i < cnt; ++i) {     // (a lane's own list: lanes run out at different i)
+                const uint32_t e = lst[(2u * i) * stride], scb = lst[(2u * i + 1u) * stride];
+                if (!(__builtin_bit_cast(float, scb) > ((e >> 31) == 0u ? thr_p : thr_n))) {
+                    lst[(2u * w) * stride] = e;      // (w <= i)
+                    lst[(2u * w + 1u) * stride] = scb;
+                    ++w;
+                }
+            }
+            cnt = w;
+        }
+    }
+    // the listed hits that are still live, oldest first (index order inside a lane)
     __device__ __forceinline__ void drain()
     {
+        if constexpr (CAP == 0) return;
+        filter();
         if constexpr (CAP == 8) {
             static_for<0, 8>([&](auto ii) {
                 constexpr uint32_t i = (uint32_t)decltype(ii)::value;
@@ -1322,19 +1346,14 @@ struct HitKeys {
                     measure(i < cnt ? (e & 0x7FFFFFFFu) : NONE, (e >> 31) == 0u, hh);
                 }
             });
-            cnt = 0u;
-        } else if constexpr (CAP != 0) {
-            const float thr_p = run_p + margin_p, thr_n = run_n + margin_n;
+        } else {
             for (uint32_t i = 0; __builtin_amdgcn_ballot_w64(i < cnt) != 0ull; ++i) {
                 const bool have = i < cnt;
                 const uint32_t e = have ? lst[(2u * i) * stride] : 0u;
-                const float sc = __builtin_bit_cast(float, have ? lst[(2u * i + 1u) * stride] : 0u);
-                const bool positive = (e >> 31) == 0u;
-                const bool keep = have && !(sc > (positive ? thr_p : thr_n));
-                if (__builtin_amdgcn_ballot_w64(keep) != 0ull) measure(keep ? (e & 0x7FFFFFFFu) : NONE, positive, hh);
+                measure(have ? (e & 0x7FFFFFFFu) : NONE, (e >> 31) == 0u, hh);
             }
-            cnt = 0u;
         }
+        cnt = 0u;
     }
     template <int PRE>
     __device__ __forceinline__ void tile(f32x16 &sc, uint32_t tile_id, const float *tail, uint32_t label, int h)
@@ -1379,6 +1398,16 @@ struct HitKeys {
         };
         if constexpr (CAP == 8) {
             const uint32_t n = (uint32_t)__builtin_popcount(hm);
+            // The register list keeps no scores, but every entry scores at least the running minimum of the moment the
+            // list last grew (`listed_at`: an entry is never below the minimum of its own moment, and the minimum only
+            // falls).  Once the minimum has come down by more than the margin since then, ALL entries lie above minimum +
+            // margin and can never qualify: the lane's list starts over.  Before the sample's true neighbourhood turns up,
+            // every tile with a new minimum lists a row -- this is what keeps those out of the drain's steps.  (A lane that
+            // serves both searches keeps two minima for one list and does not do this.)
+            if (en_p != en_n) {
+                if ((en_p ? thr_p : thr_n) < listed_at) cnt = 0u;
+                if (hm != 0u) listed_at = en_p ? run_p : run_n;
+            }
             if (__builtin_amdgcn_ballot_w64(cnt + n > 8u) != 0ull) drain();
             if (__builtin_amdgcn_ballot_w64(n > 8u) != 0ull) {
                 each_hit([&](uint32_t mine, bool positive) { measure(mine, positive, h); });
@@ -1391,6 +1420,7 @@ struct HitKeys {
                 });
             }
         } else if constexpr (CAP != 0) {
+            if (__builtin_amdgcn_ballot_w64(cnt + (uint32_t)__builtin_popcount(hm) > (uint32_t)CAP) != 0ull) filter();
             if (__builtin_amdgcn_ballot_w64(cnt + (uint32_t)__builtin_popcount(hm) > (uint32_t)CAP) != 0ull) drain();
 #pragma unroll
             for (int o = 0; o < 16; ++o) {
