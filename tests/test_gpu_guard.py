@@ -141,6 +141,34 @@ def test_a_long_run_of_near_copies(ctx, K, D, copies):
     _check(ctx, X, W, cls=cls, y=y)
 
 
+@pytest.mark.parametrize("step", [2e-6, 2e-5, 2e-4], ids=lambda v: f"{v:g}")
+@pytest.mark.parametrize("K,D", [(256, 128), (2048, 128), (96, 64)], ids=lambda v: str(v))
+def test_a_staircase_of_falling_distances(ctx, K, D, step):
+    """Prototypes on shells around one point whose squared radius falls by `step` (relative) from one index to the next:
+    the running minimum of the finish pass comes down a little with every row -- by less than the screening margin per
+    tile at 2e-6, by about the margin at 2e-5, by several margins at 2e-4 -- so its hit lists fill, are filtered against
+    the thresholds of the moment, restart (HitKeys: `listed_at`) and drain at every boundary of those rules, while the
+    winner is the LAST row of the staircase and a few exact copies of it further on must lose to the lowest index."""
+    rng = np.random.default_rng(int(step * 1e7) + K + D)
+    x0 = rng.uniform(-1, 1, size=D)
+    r0 = 0.5 * np.linalg.norm(x0)
+    u = rng.normal(size=(K, D))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    top = K - K // 8                                              # the staircase ends here; the rows behind it lie further out
+    r2 = r0 * r0 * (1.0 + step * (top - np.arange(K)))
+    r2[top:] = r0 * r0 * (1.5 + rng.uniform(0, 1, size=K - top))
+    W = (x0 + np.sqrt(r2)[:, None] * u).astype(np.float32)
+    W[top + 1] = W[top - 1]                                       # exact copies of the winner at higher indices
+    W[K - 1] = W[top - 1]
+    N = 2500
+    X = rng.uniform(-1, 1, size=(N, D)).astype(np.float32)
+    near = rng.integers(0, N, size=(2 * N) // 3)
+    X[near] = (x0 + 1e-4 * r0 * rng.normal(size=(len(near), D))).astype(np.float32)
+    cls = (np.arange(K) % 3).astype(np.uint32)
+    y = rng.integers(0, 3, size=N).astype(np.uint32)
+    _check(ctx, X, W, cls=cls, y=y)
+
+
 @pytest.mark.parametrize("D,K", [(1, 5000), (1, 300), (2, 3000), (3, 4000)], ids=lambda v: str(v))
 def test_many_prototypes_in_few_dimensions(ctx, D, K):
     """Thousands of prototypes on a line / in a plane / in space: dense by counting.  Round 1: scalar kernels."""
